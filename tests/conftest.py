@@ -1,0 +1,26 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def trie_golden():
+    with open(os.path.join(GOLD, "trie_cases.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def balancer_golden():
+    with open(os.path.join(GOLD, "balancer_cases.json")) as f:
+        return json.load(f)
