@@ -1,0 +1,47 @@
+"""ctypes binding of libdta_mi355x.so (include/dta.h).  There is no fallback: every entry point
+raises if the library is missing or a call returns a non-zero status."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB
+
+_lib = None
+_i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+_PROTOS = {
+    "dta_version": ([], C.c_int),
+    "dta_lcp_adjacent": ([_vp, _vp, _i32, _vp, _vp, _vp], C.c_int),
+    "dta_leafize": ([_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp], C.c_int),
+    "dta_preorder_meta": ([_vp] * 8 + [_i32, _i32] + [_vp] * 4 + [_vp], C.c_int),
+    "dta_tree_attn_fwd": ([_vp] * 8 + [_i32] * 6 + [_i64] * 3 + [_f32, _i32, _vp], C.c_int),
+    "dta_tree_attn_bwd": ([_vp] * 14 + [_i32] * 6 + [_i64] * 5 + [_f32, _i32, _i32, _vp], C.c_int),
+    "dta_tree_attn_fwd_ex": ([_vp] * 8 + [_i32] * 6 + [_i64] * 6 + [_f32, _i32, _vp], C.c_int),
+    "dta_tree_attn_bwd_ex": ([_vp] * 14 + [_i32] * 6 + [_i64] * 10 + [_f32, _i32, _i32, _vp], C.c_int),
+}
+EXPORTS = tuple(_PROTOS)
+_ERR = {-1: "DTA_EINVAL", -2: "DTA_EUNSUPPORTED", -3: "DTA_EALIGN", -4: "DTA_ELAUNCH"}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise RuntimeError(f"{LIB} is missing: run `python -m dynamictreeattn_amd.build` (hipcc, gfx950). "
+                               "There is no CPU fallback for the hot path.")
+        l = C.CDLL(LIB)
+        for name, (args, res) in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.argtypes, fn.restype = args, res
+        _lib = l
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise RuntimeError(f"{what} failed: {_ERR.get(status, status)}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,584 @@
+// Tree attention forward / backward for gfx950 (MI355X, CDNA4).  head_dim = 128, bf16 or f16.
+//
+// One kernel family serves both forms of the reference's "node attends to its ancestor path":
+//   * packed trie (DFS pre-order): key s visible to query t  <=>  s <= t < subtree_end[s]
+//   * stack form (tree_training_engine.py:171-186): subtree_end == NULL, q_offset = start
+//
+// Tiling (wave64, v_mfma_f32_32x32x16):
+//   fwd / dQ : workgroup = 4 waves = 128 query rows of one query head; each wave owns 32 rows with the
+//              QUERY ON THE MFMA LANE (S^T = K·Q^T), so the softmax row statistics are lane-local and
+//              the S^T accumulator is directly the B operand of O^T += V^T·P^T / dQ^T += K^T·dS^T.
+//   dK/dV    : workgroup = 4 waves = 128 keys of one kv head; each wave owns 32 keys with the KEY ON
+//              THE LANE (S = Q·K^T), dK^T/dV^T live in 128 accumulator registers per wave across the whole
+//              query sweep (all query heads of the GQA group) -> no cross-workgroup sum, no atomics.
+//   K/V (resp. Q/dO) tiles of 64 rows x 128 cols are staged global -> registers -> LDS (issue early,
+//   write late) into one swizzled 256-B-row image that serves BOTH row reads (ds_read_b128) and
+//   transposed reads (ds_read_b64_tr_b16).
+//
+// Lane maps used here were verified on hardware by tests/micro/mfma_layout_probe.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dta.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
+template <int DT> struct Ty;
+template <> struct Ty<DTA_BF16> {
+  using e = __bf16; using v8 = bf16x8; using v4 = bf16x4;
+  static __device__ __forceinline__ f32x16 mma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Ty<DTA_F16> {
+  using e = _Float16; using v8 = f16x8; using v4 = f16x4;
+  static __device__ __forceinline__ f32x16 mma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+struct AttnParams {
+  const void *q, *k, *v, *o, *dout;
+  void *out, *dq, *dk, *dv;
+  float *lse_w; const float* lse_r; float* delta;
+  const int32_t *subtree_end, *run_ptr, *runs, *ktile_qend;
+  int32_t Tq, Tk, q_offset, Hq, Hkv, group;
+  int64_t q_st, q_sh, kv_st, kv_sh, o_st, o_sh, dq_st, dq_sh, dkv_st, dkv_sh;
+  float scale; int32_t accumulate;
+};
+
+constexpr int TILE_BYTES = 64 * 256;           // 64 rows x 128 x 2 B
+constexpr float LOG2E = 1.4426950408889634f;
+
+// Byte offset of 16-B chunk `ch` (0..15) of row `row` in a [rows][128 x 16-bit] image with 256-B rows.
+// The XOR makes both the 32x32x16 row reads (ds_read_b128) and the transposed reads conflict-free.
+__device__ __forceinline__ int img_off(int row, int ch) {
+  return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+template <class V8> __device__ __forceinline__ V8 row_frag(const char* img, int row, int ch) {
+  return *reinterpret_cast<const V8*>(img + img_off(row, ch));
+}
+
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+// A-operand fragment read TRANSPOSED from the image: A[m = 32*mb + (lane&31)][kk], where the 16-deep
+// k-step covers image rows R0..R0+15 in the accumulator-as-operand order
+// (element j of lane half h <-> image row R0 + 8*(j>>2) + 4*h + (j&3)) and m indexes image columns.
+template <class V8> __device__ __forceinline__ V8 tr_frag(const char* img, int R0, int mb, int lane) {
+  const int G = lane >> 4, hh = lane >> 5, i = lane & 15, qd = i >> 2, p = i & 3;
+  const int ch = 4 * mb + 2 * (G & 1) + (p >> 1);
+  const int ra = R0 + 4 * hh + qd;
+  s16x4 lo = tr_read(img + img_off(ra, ch) + 8 * (p & 1));
+  s16x4 hi = tr_read(img + img_off(ra + 8, ch) + 8 * (p & 1));
+  s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(V8, both);
+}
+
+// accumulator registers 8*s2 .. 8*s2+7 -> 16-bit fragment of k-step s2 (s2 = 0,1) of a 32-row block
+template <int DT> __device__ __forceinline__ typename Ty<DT>::v8 pack_half(const f32x16& x, int s2) {
+  typename Ty<DT>::v8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (typename Ty<DT>::e)x[8 * s2 + j];
+  return r;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// ---- iterator over the 64-key tiles of a query tile's run list --------------------------------
+struct TileIter {
+  const int32_t* runs; int ri, re;      // run cursor
+  int k0, kend, flag;                   // current tile
+  int diag_first_q;                     // NULL-run mode: packed index of the tile's first query
+  __device__ __forceinline__ bool load_run() {
+    while (ri < re) {
+      k0 = runs[4 * ri]; kend = runs[4 * ri + 1]; flag = runs[4 * ri + 2];
+      if (k0 < kend) return true;
+      ++ri;
+    }
+    return false;
+  }
+  __device__ __forceinline__ bool advance() {          // to the next tile; false when exhausted
+    k0 += 64;
+    if (k0 < kend) return true;
+    if (runs == nullptr) return false;
+    ++ri;
+    return load_run();
+  }
+  __device__ __forceinline__ bool masked() const {
+    if (runs == nullptr) return (k0 + 63 > diag_first_q) || (k0 + 64 > kend);
+    return flag != 0 || (k0 + 64 > kend);
+  }
+};
+
+// =================================================================================================
+// forward
+// =================================================================================================
+template <int DT>
+__global__ __launch_bounds__(256) void tree_attn_fwd_kernel(AttnParams p) {
+  using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 256];
+  char* Ks = smem; char* Vs = smem + TILE_BYTES; int* se_s = reinterpret_cast<int*>(smem + 2 * TILE_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int bid = blockIdx.x;
+  const int kvh = bid % p.Hkv; const int rest = bid / p.Hkv; const int hg = rest % p.group; const int qt = rest / p.group;
+  const int hq = kvh * p.group + hg;
+  const int q0 = qt * DTA_QTILE;
+  const int qrow = q0 + wave * 32 + r;
+  const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
+  const int qidx = p.q_offset + qrow;
+
+  TileIter it; it.runs = p.runs; it.diag_first_q = p.q_offset + q0;
+  if (p.runs) { it.ri = p.run_ptr[qt]; it.re = p.run_ptr[qt + 1]; if (!it.load_run()) return; }
+  else { it.ri = 0; it.re = 1; it.k0 = 0; it.flag = 1; int last = p.q_offset + (q0 + DTA_QTILE < p.Tq ? q0 + DTA_QTILE : p.Tq); it.kend = last < p.Tk ? last : p.Tk; if (it.kend <= 0) return; }
+
+  const e* qp = reinterpret_cast<const e*>(p.q) + (int64_t)qrow_c * p.q_st + (int64_t)hq * p.q_sh;
+  v8 qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const v8*>(qp + 16 * s + 8 * h);
+
+  const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
+  const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.kv_sh;
+
+  uint4 kreg[4], vreg[4]; int sereg = 0;
+  auto stage_load = [&](int k0, int kend) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
+      int kr = k0 + row; kr = kr < p.Tk ? kr : p.Tk - 1;
+      kreg[i] = *reinterpret_cast<const uint4*>(kbase + (int64_t)kr * p.kv_st + ch * 8);
+      vreg[i] = *reinterpret_cast<const uint4*>(vbase + (int64_t)kr * p.kv_st + ch * 8);
+    }
+    if (tid < 64) { const int ki = k0 + tid; sereg = (ki < kend) ? (p.subtree_end ? p.subtree_end[ki] : 0x7fffffff) : 0; }
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
+      *reinterpret_cast<uint4*>(Ks + img_off(row, ch)) = kreg[i];
+      *reinterpret_cast<uint4*>(Vs + img_off(row, ch)) = vreg[i];
+    }
+    if (tid < 64) se_s[tid] = sereg;
+  };
+
+  f32x16 O[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) O[db][g] = 0.f;
+  float m = -1e30f, lsum = 0.f;
+  const float c = p.scale * LOG2E;
+
+  stage_load(it.k0, it.kend); stage_write(); __syncthreads();
+  int ck0 = it.k0; bool cmask = it.masked();
+  while (true) {
+    const bool has_next = it.advance();
+    if (has_next) stage_load(it.k0, it.kend);
+
+    // ---- S^T[key][q] = K · Q^T -----------------------------------------------------------------
+    f32x16 X[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) X[kb][g] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) X[kb] = T::mma(row_frag<v8>(Ks, 32 * kb + r, 2 * s + h), qf[s], X[kb]);
+    }
+    // ---- mask + online softmax (log2 domain) ---------------------------------------------------
+    float mx = -INFINITY;
+    if (cmask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int kl = 32 * kb + 8 * (g >> 2) + 4 * h + (g & 3);
+          const bool ok = (ck0 + kl <= qidx) && (qidx < se_s[kl]);
+          const float t = ok ? X[kb][g] * c : -INFINITY;
+          X[kb][g] = t; mx = fmaxf(mx, t);
+        }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { const float t = X[kb][g] * c; X[kb][g] = t; mx = fmaxf(mx, t); }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(m, mx);
+    const float alpha = fast_exp2(m - mnew);
+    m = mnew; lsum *= alpha;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) O[db][g] *= alpha;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) { const float pv = fast_exp2(X[kb][g] - mnew); lsum += pv; X[kb][g] = pv; }
+    // ---- O^T[d][q] += V^T · P^T ------------------------------------------------------------------
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const v8 pb = pack_half<DT>(X[s4 >> 1], s4 & 1);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) O[db] = T::mma(tr_frag<v8>(Vs, 16 * s4, db, lane), pb, O[db]);
+    }
+    __syncthreads();
+    if (!has_next) break;
+    stage_write(); __syncthreads();
+    ck0 = it.k0; cmask = it.masked();
+  }
+
+  lsum += __shfl_xor(lsum, 32);
+  const float inv = 1.f / lsum;
+  if (qrow < p.Tq) {
+    e* op = reinterpret_cast<e*>(p.out) + (int64_t)qrow * p.o_st + (int64_t)hq * p.o_sh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        v4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (e)(O[db][4 * gq + j] * inv);
+        *reinterpret_cast<v4*>(op + 32 * db + 8 * gq + 4 * h) = w;
+      }
+    if (h == 0) p.lse_w[(int64_t)qrow * p.Hq + hq] = m + __builtin_amdgcn_logf(lsum);   // v_log_f32 = log2
+  }
+}
+
+// =================================================================================================
+// backward part 1: delta + dQ   (query tile owns the workgroup; same sweep as the forward)
+// =================================================================================================
+template <int DT>
+__global__ __launch_bounds__(256) void tree_attn_bwd_dq_kernel(AttnParams p) {
+  using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 256];
+  char* Ks = smem; char* Vs = smem + TILE_BYTES; int* se_s = reinterpret_cast<int*>(smem + 2 * TILE_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int bid = blockIdx.x;
+  const int kvh = bid % p.Hkv; const int rest = bid / p.Hkv; const int hg = rest % p.group; const int qt = rest / p.group;
+  const int hq = kvh * p.group + hg;
+  const int q0 = qt * DTA_QTILE;
+  const int qrow = q0 + wave * 32 + r;
+  const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
+  const int qidx = p.q_offset + qrow;
+
+  const e* qp = reinterpret_cast<const e*>(p.q) + (int64_t)qrow_c * p.q_st + (int64_t)hq * p.q_sh;
+  const e* dop = reinterpret_cast<const e*>(p.dout) + (int64_t)qrow_c * p.o_st + (int64_t)hq * p.o_sh;
+  const e* op = reinterpret_cast<const e*>(p.o) + (int64_t)qrow_c * p.o_st + (int64_t)hq * p.o_sh;
+  v8 qf[8], dof[8];
+  float dsum = 0.f;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    qf[s] = *reinterpret_cast<const v8*>(qp + 16 * s + 8 * h);
+    dof[s] = *reinterpret_cast<const v8*>(dop + 16 * s + 8 * h);
+    const v8 of = *reinterpret_cast<const v8*>(op + 16 * s + 8 * h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsum += (float)dof[s][j] * (float)of[j];
+  }
+  dsum += __shfl_xor(dsum, 32);
+  const float delta = dsum;
+  const float lse2 = p.lse_r[(int64_t)qrow_c * p.Hq + hq];
+  if (h == 0 && qrow < p.Tq) p.delta[(int64_t)qrow * p.Hq + hq] = delta;
+
+  TileIter it; it.runs = p.runs; it.diag_first_q = p.q_offset + q0;
+  bool any = true;
+  if (p.runs) { it.ri = p.run_ptr[qt]; it.re = p.run_ptr[qt + 1]; any = it.load_run(); }
+  else { it.ri = 0; it.re = 1; it.k0 = 0; it.flag = 1; int last = p.q_offset + (q0 + DTA_QTILE < p.Tq ? q0 + DTA_QTILE : p.Tq); it.kend = last < p.Tk ? last : p.Tk; any = it.kend > 0; }
+
+  const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
+  const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.kv_sh;
+  uint4 kreg[4], vreg[4]; int sereg = 0;
+  auto stage_load = [&](int k0, int kend) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
+      int kr = k0 + row; kr = kr < p.Tk ? kr : p.Tk - 1;
+      kreg[i] = *reinterpret_cast<const uint4*>(kbase + (int64_t)kr * p.kv_st + ch * 8);
+      vreg[i] = *reinterpret_cast<const uint4*>(vbase + (int64_t)kr * p.kv_st + ch * 8);
+    }
+    if (tid < 64) { const int ki = k0 + tid; sereg = (ki < kend) ? (p.subtree_end ? p.subtree_end[ki] : 0x7fffffff) : 0; }
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
+      *reinterpret_cast<uint4*>(Ks + img_off(row, ch)) = kreg[i];
+      *reinterpret_cast<uint4*>(Vs + img_off(row, ch)) = vreg[i];
+    }
+    if (tid < 64) se_s[tid] = sereg;
+  };
+
+  f32x16 DQ[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) DQ[db][g] = 0.f;
+  const float c = p.scale * LOG2E;
+
+  if (any) {
+    stage_load(it.k0, it.kend); stage_write(); __syncthreads();
+    int ck0 = it.k0;
+    while (true) {
+      const bool has_next = it.advance();
+      if (has_next) stage_load(it.k0, it.kend);
+      f32x16 X[2], DP[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { X[kb][g] = 0.f; DP[kb][g] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          X[kb] = T::mma(row_frag<v8>(Ks, 32 * kb + r, 2 * s + h), qf[s], X[kb]);
+          DP[kb] = T::mma(row_frag<v8>(Vs, 32 * kb + r, 2 * s + h), dof[s], DP[kb]);
+        }
+      }
+      // dS^T = P ∘ (dP − delta) · scale   (always masked: cheap next to 48 MFMAs, and exact zeros matter)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int kl = 32 * kb + 8 * (g >> 2) + 4 * h + (g & 3);
+          const bool ok = (ck0 + kl <= qidx) && (qidx < se_s[kl]);
+          const float pv = ok ? fast_exp2(X[kb][g] * c - lse2) : 0.f;
+          X[kb][g] = pv * (DP[kb][g] - delta) * p.scale;
+        }
+      // dQ^T[d][q] += K^T · dS^T
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const v8 db_ = pack_half<DT>(X[s4 >> 1], s4 & 1);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) DQ[db] = T::mma(tr_frag<v8>(Ks, 16 * s4, db, lane), db_, DQ[db]);
+      }
+      __syncthreads();
+      if (!has_next) break;
+      stage_write(); __syncthreads();
+      ck0 = it.k0;
+    }
+  }
+  if (qrow < p.Tq) {
+    e* dqp = reinterpret_cast<e*>(p.dq) + (int64_t)qrow * p.dq_st + (int64_t)hq * p.dq_sh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        v4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (e)DQ[db][4 * gq + j];
+        *reinterpret_cast<v4*>(dqp + 32 * db + 8 * gq + 4 * h) = w;
+      }
+  }
+}
+
+// =================================================================================================
+// backward part 2: dK, dV   (key tile owns the workgroup)
+// =================================================================================================
+template <int DT>
+__global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
+  using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 512];
+  char* Qs = smem; char* Ds = smem + TILE_BYTES;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * TILE_BYTES); float* del_s = lse_s + 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int bid = blockIdx.x;
+  const int kvh = bid % p.Hkv; const int kt = bid / p.Hkv;
+  const int k0 = kt * DTA_KTILE;
+  const int kidx = k0 + wave * 32 + r;
+  const int kidx_c = kidx < p.Tk ? kidx : p.Tk - 1;
+  const int q_hi = p.q_offset + p.Tq;
+  int se_l = (kidx < p.Tk) ? (p.subtree_end ? p.subtree_end[kidx] : 0x7fffffff) : 0;
+  se_l = se_l < q_hi ? se_l : q_hi;
+
+  const e* kp = reinterpret_cast<const e*>(p.k) + (int64_t)kidx_c * p.kv_st + (int64_t)kvh * p.kv_sh;
+  const e* vp = reinterpret_cast<const e*>(p.v) + (int64_t)kidx_c * p.kv_st + (int64_t)kvh * p.kv_sh;
+  v8 kf[8], vf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { kf[s] = *reinterpret_cast<const v8*>(kp + 16 * s + 8 * h); vf[s] = *reinterpret_cast<const v8*>(vp + 16 * s + 8 * h); }
+
+  f32x16 DK[4], DV[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { DK[db][g] = 0.f; DV[db][g] = 0.f; }
+
+  int qbeg = k0 > p.q_offset ? k0 : p.q_offset;                      // packed index of the first query that can see a key here
+  int qend = p.ktile_qend ? p.ktile_qend[kt] : q_hi; qend = qend < q_hi ? qend : q_hi;
+  const int ntile = qend > qbeg ? (qend - qbeg + 63) / 64 : 0;
+  const int total = ntile * p.group;
+  const float c = p.scale * LOG2E;
+
+  uint4 qreg[4], dreg[4]; float lreg = 0.f, dlreg = 0.f;
+  auto stage_load = [&](int idx) {
+    const int hg = idx / ntile, ti = idx - hg * ntile;
+    const int hq = kvh * p.group + hg;
+    const int row0 = qbeg + 64 * ti - p.q_offset;
+    const e* qb = reinterpret_cast<const e*>(p.q) + (int64_t)hq * p.q_sh;
+    const e* db = reinterpret_cast<const e*>(p.dout) + (int64_t)hq * p.o_sh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
+      int qr = row0 + row; qr = qr < p.Tq ? qr : p.Tq - 1;
+      qreg[i] = *reinterpret_cast<const uint4*>(qb + (int64_t)qr * p.q_st + ch * 8);
+      dreg[i] = *reinterpret_cast<const uint4*>(db + (int64_t)qr * p.o_st + ch * 8);
+    }
+    if (tid < 64) { int qr = row0 + tid; qr = qr < p.Tq ? qr : p.Tq - 1; lreg = p.lse_r[(int64_t)qr * p.Hq + hq]; dlreg = p.delta[(int64_t)qr * p.Hq + hq]; }
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
+      *reinterpret_cast<uint4*>(Qs + img_off(row, ch)) = qreg[i];
+      *reinterpret_cast<uint4*>(Ds + img_off(row, ch)) = dreg[i];
+    }
+    if (tid < 64) { lse_s[tid] = lreg; del_s[tid] = dlreg; }
+  };
+
+  if (total > 0) {
+    stage_load(0); stage_write(); __syncthreads();
+    for (int idx = 0; idx < total; ++idx) {
+      const bool has_next = idx + 1 < total;
+      if (has_next) stage_load(idx + 1);
+      const int ti = idx % ntile;
+      const int qi0 = qbeg + 64 * ti;                                   // packed index of image row 0
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x16 S, DP;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { S[g] = 0.f; DP[g] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          S = T::mma(row_frag<v8>(Qs, 32 * qb + r, 2 * s + h), kf[s], S);
+          DP = T::mma(row_frag<v8>(Ds, 32 * qb + r, 2 * s + h), vf[s], DP);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int ql = 32 * qb + 8 * (g >> 2) + 4 * h + (g & 3);
+          const int qi = qi0 + ql;
+          const bool ok = (kidx <= qi) && (qi < se_l);
+          const float pv = ok ? fast_exp2(S[g] * c - lse_s[ql]) : 0.f;
+          S[g] = pv;
+          DP[g] = pv * (DP[g] - del_s[ql]) * p.scale;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const v8 pb = pack_half<DT>(S, s2);
+          const v8 sb = pack_half<DT>(DP, s2);
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            DV[db] = T::mma(tr_frag<v8>(Ds, 32 * qb + 16 * s2, db, lane), pb, DV[db]);
+            DK[db] = T::mma(tr_frag<v8>(Qs, 32 * qb + 16 * s2, db, lane), sb, DK[db]);
+          }
+        }
+      }
+      __syncthreads();
+      if (has_next) { stage_write(); __syncthreads(); }
+    }
+  }
+  if (kidx < p.Tk) {
+    e* dkp = reinterpret_cast<e*>(p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+    e* dvp = reinterpret_cast<e*>(p.dv) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = 32 * db + 8 * gq + 4 * h;
+        v4 wk, wv;
+        if (p.accumulate) {
+          const v4 ok_ = *reinterpret_cast<const v4*>(dkp + d); const v4 ov_ = *reinterpret_cast<const v4*>(dvp + d);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { wk[j] = (e)(DK[db][4 * gq + j] + (float)ok_[j]); wv[j] = (e)(DV[db][4 * gq + j] + (float)ov_[j]); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { wk[j] = (e)DK[db][4 * gq + j]; wv[j] = (e)DV[db][4 * gq + j]; }
+        }
+        *reinterpret_cast<v4*>(dkp + d) = wk;
+        *reinterpret_cast<v4*>(dvp + d) = wv;
+      }
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse,
+                                    const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
+                                    int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                                    int64_t q_st, int64_t q_sh, int64_t kv_st, int64_t kv_sh, int64_t o_st, int64_t o_sh,
+                                    float scale, int32_t dtype, void* stream) {
+  if (!q || !k || !v || !out || !lse || Tq <= 0 || Tk <= 0 || Hq <= 0 || Hkv <= 0 || q_offset < 0) return DTA_EINVAL;
+  if ((runs == nullptr) != (run_ptr == nullptr)) return DTA_EINVAL;
+  if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16)) return DTA_EUNSUPPORTED;
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || (q_st | q_sh | kv_st | kv_sh | o_st | o_sh) % 8 != 0) return DTA_EALIGN;
+  AttnParams p{};
+  p.q = q; p.k = k; p.v = v; p.out = out; p.lse_w = lse; p.subtree_end = subtree_end; p.run_ptr = run_ptr; p.runs = runs;
+  p.Tq = Tq; p.Tk = Tk; p.q_offset = q_offset; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
+  p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.o_st = o_st; p.o_sh = o_sh; p.scale = scale;
+  const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
+  dim3 grid(nqt * Hq), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == DTA_BF16) hipLaunchKernelGGL(tree_attn_fwd_kernel<DTA_BF16>, grid, block, 0, st, p);
+  else hipLaunchKernelGGL(tree_attn_fwd_kernel<DTA_F16>, grid, block, 0, st, p);
+  return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
+}
+
+extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                                    const float* lse, float* delta, void* dq, void* dk, void* dv,
+                                    const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
+                                    const int32_t* ktile_qend,
+                                    int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                                    int64_t q_st, int64_t q_sh, int64_t kv_st, int64_t kv_sh, int64_t o_st, int64_t o_sh,
+                                    int64_t dq_st, int64_t dq_sh, int64_t dkv_st, int64_t dkv_sh,
+                                    float scale, int32_t dtype, int32_t accumulate, void* stream) {
+  if (!q || !k || !v || !out || !dout || !lse || !delta || !dq || !dk || !dv || Tq <= 0 || Tk <= 0 || Hq <= 0 || Hkv <= 0 || q_offset < 0) return DTA_EINVAL;
+  if ((runs == nullptr) != (run_ptr == nullptr)) return DTA_EINVAL;
+  if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16)) return DTA_EUNSUPPORTED;
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) ||
+      (q_st | q_sh | kv_st | kv_sh | o_st | o_sh | dq_st | dq_sh | dkv_st | dkv_sh) % 8 != 0) return DTA_EALIGN;
+  AttnParams p{};
+  p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse_r = lse; p.delta = delta; p.dq = dq; p.dk = dk; p.dv = dv;
+  p.subtree_end = subtree_end; p.run_ptr = run_ptr; p.runs = runs; p.ktile_qend = ktile_qend;
+  p.Tq = Tq; p.Tk = Tk; p.q_offset = q_offset; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
+  p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.o_st = o_st; p.o_sh = o_sh;
+  p.dq_st = dq_st; p.dq_sh = dq_sh; p.dkv_st = dkv_st; p.dkv_sh = dkv_sh; p.scale = scale; p.accumulate = accumulate;
+  const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
+  const int nkt = (Tk + DTA_KTILE - 1) / DTA_KTILE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == DTA_BF16) {
+    hipLaunchKernelGGL(tree_attn_bwd_dq_kernel<DTA_BF16>, dim3(nqt * Hq), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_BF16>, dim3(nkt * Hkv), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(tree_attn_bwd_dq_kernel<DTA_F16>, dim3(nqt * Hq), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_F16>, dim3(nkt * Hkv), dim3(256), 0, st, p);
+  }
+  return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
+}
+
+// Token-major convenience forms declared in dta.h: head stride = 128 elements.
+extern "C" int dta_tree_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+                                 const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
+                                 int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                                 int64_t q_stride_t, int64_t kv_stride_t, int64_t o_stride_t,
+                                 float scale, int32_t dtype, void* stream) {
+  return dta_tree_attn_fwd_ex(q, k, v, out, lse, subtree_end, run_ptr, runs, Tq, Tk, q_offset, Hq, Hkv, head_dim,
+                              q_stride_t, 128, kv_stride_t, 128, o_stride_t, 128, scale, dtype, stream);
+}
+
+extern "C" int dta_tree_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                                 const float* lse, float* delta, void* dq, void* dk, void* dv,
+                                 const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
+                                 const int32_t* ktile_qend,
+                                 int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                                 int64_t q_stride_t, int64_t kv_stride_t, int64_t o_stride_t,
+                                 int64_t dq_stride_t, int64_t dkv_stride_t,
+                                 float scale, int32_t dtype, int32_t accumulate, void* stream) {
+  return dta_tree_attn_bwd_ex(q, k, v, out, dout, lse, delta, dq, dk, dv, subtree_end, run_ptr, runs, ktile_qend,
+                              Tq, Tk, q_offset, Hq, Hkv, head_dim, q_stride_t, 128, kv_stride_t, 128, o_stride_t, 128,
+                              dq_stride_t, 128, dkv_stride_t, 128, scale, dtype, accumulate, stream);
+}

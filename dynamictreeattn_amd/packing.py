@@ -1,0 +1,151 @@
+"""Host-side planning of the packed (DFS pre-order) trie layout.
+
+Given the leaves of a TokenTrie in their current DFS order — ``lens[M]`` and ``lcp_lens[M-1]`` —
+leaf i contributes the *segment* of its tokens at depths ``[lcp[i-1], len[i])``; segments are laid
+back to back, so a token's packed index is ``seg_off[i] + depth - lcp[i-1]`` and its RoPE position
+is its depth (the stack position of tree_training_engine.py:166, 293).
+
+This module only produces O(M·height) integer tables on the host; the per-token arrays
+(token id, depth, parent, subtree_end) are expanded on the GPU by ``dta_preorder_meta``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+QTILE = 128
+KTILE = 128
+
+
+@dataclass
+class SegmentPlan:
+    M: int
+    T: int
+    seg_off: np.ndarray          # int32 [M+1]
+    seg_depth0: np.ndarray       # int32 [M]   depth of the segment's first token (= lcp with the previous leaf)
+    parent_of_seg: np.ndarray    # int32 [M]   packed index of the token above the segment's first token (-1 at the root)
+    brk_ptr: np.ndarray          # int32 [M+1]
+    brk_depth: np.ndarray        # int32 [nbrk] ascending per segment; first entry == seg_depth0
+    brk_end: np.ndarray          # int32 [nbrk] subtree_end of the segment's tokens at depth >= brk_depth (until the next break)
+    path_runs: List[List[Tuple[int, int]]]   # per segment: packed [begin,end) runs of its ancestors, root first
+
+
+def plan_segments(lens: Sequence[int], lcp_lens: Sequence[int]) -> SegmentPlan:
+    M = len(lens)
+    if len(lcp_lens) != M - 1:
+        raise ValueError("lcp_lens must have len(lens)-1 entries")
+    d0 = [0] + [int(c) for c in lcp_lens]
+    seg_off = [0] * (M + 1)
+    for i in range(M):
+        if not (0 <= d0[i] <= lens[i]) or (i > 0 and d0[i] > lens[i - 1]):
+            raise ValueError("lcp_lens inconsistent with lens")
+        seg_off[i + 1] = seg_off[i] + (lens[i] - d0[i])
+    T = seg_off[M]
+    live: List[List[int]] = []            # [segment, depth_lo, depth_hi) intervals on the current root->leaf path
+    brk: List[List[Tuple[int, int]]] = [[] for _ in range(M)]
+    parent = [-1] * M
+    path_runs: List[List[Tuple[int, int]]] = []
+    for i in range(M):
+        cut, here = d0[i], seg_off[i]
+        while live and live[-1][1] >= cut:            # whole interval diverges: its tokens end their subtree here
+            j, lo, _ = live.pop()
+            brk[j].append((lo, here))
+        if live and live[-1][2] > cut:                # partial: depths >= cut end here
+            live[-1][2] = cut
+            brk[live[-1][0]].append((cut, here))
+        runs = []
+        for j, lo, hi in live:
+            b, e = seg_off[j] + lo - d0[j], seg_off[j] + hi - d0[j]
+            if runs and runs[-1][1] == b:
+                runs[-1] = (runs[-1][0], e)
+            else:
+                runs.append((b, e))
+        path_runs.append(runs)
+        if cut > 0:
+            j, lo, hi = live[-1]
+            parent[i] = seg_off[j] + (cut - 1) - d0[j]
+        if lens[i] > cut:
+            live.append([i, cut, lens[i]])
+    for j, lo, _ in live:
+        brk[j].append((lo, T))
+    ptr = [0]
+    bd: List[int] = []
+    be: List[int] = []
+    for j in range(M):
+        ent = brk[j][::-1]                            # closing order is deepest first
+        # merge duplicates of the same depth (a truncated-to-empty interval closes twice at one depth)
+        clean: List[Tuple[int, int]] = []
+        for dep, end in ent:
+            if clean and clean[-1][0] == dep:
+                continue
+            clean.append((dep, end))
+        if not clean:                                 # empty segment (leaf equal to a prefix of the previous): keep one dummy
+            clean = [(d0[j], seg_off[j])]
+        bd += [c[0] for c in clean]; be += [c[1] for c in clean]
+        ptr.append(len(bd))
+    return SegmentPlan(M, T, np.asarray(seg_off, np.int32), np.asarray(d0, np.int32), np.asarray(parent, np.int32),
+                       np.asarray(ptr, np.int32), np.asarray(bd, np.int32), np.asarray(be, np.int32), path_runs)
+
+
+def expand_plan_host(plan: SegmentPlan):
+    """numpy mirror of dta_preorder_meta's index arithmetic (tests and CPU-side planning checks only;
+    the engine uses the HIP kernel).  Returns (seg_of_token, depth, parent, subtree_end)."""
+    T, M = plan.T, plan.M
+    seg = np.repeat(np.arange(M, dtype=np.int32), np.diff(plan.seg_off))
+    j = np.arange(T, dtype=np.int32) - plan.seg_off[seg]
+    depth = plan.seg_depth0[seg] + j
+    parent = np.where(j > 0, np.arange(T, dtype=np.int32) - 1, plan.parent_of_seg[seg]).astype(np.int32)
+    se = np.empty(T, np.int32)
+    for i in range(M):
+        a, b = plan.brk_ptr[i], plan.brk_ptr[i + 1]
+        s, e = plan.seg_off[i], plan.seg_off[i + 1]
+        if e > s:
+            k = np.searchsorted(plan.brk_depth[a:b], depth[s:e], side="right") - 1
+            se[s:e] = plan.brk_end[a:b][k]
+    return seg, depth.astype(np.int32), parent, se
+
+
+def plan_qtile_runs(plan: SegmentPlan, tile: int = QTILE):
+    """Key runs each query tile of `tile` packed rows must visit: (run_ptr int32 [nqt+1],
+    runs int32 [nruns,4] = {key_begin, key_end, needs_mask, 0}).  A run is flagged maskless only when
+    every key in it is an ancestor of every row of the tile."""
+    T = plan.T
+    nqt = (T + tile - 1) // tile
+    seg_off = plan.seg_off
+    starts = np.arange(nqt, dtype=np.int64) * tile
+    ends = np.minimum(starts + tile, T)
+    first = np.searchsorted(seg_off, starts, side="right") - 1
+    last = np.searchsorted(seg_off, ends - 1, side="right") - 1
+    run_ptr = [0]
+    out: List[Tuple[int, int, int, int]] = []
+    for qt in range(nqt):
+        q0, q1, i0, i1 = int(starts[qt]), int(ends[qt]), int(first[qt]), int(last[qt])
+        if i0 == i1:
+            for b, e in plan.path_runs[i0]:
+                out.append((b, e, 0, 0))
+            s = int(seg_off[i0])
+            if s < q0:
+                if out and len(out) > run_ptr[-1] and out[-1][1] == s and out[-1][2] == 0:
+                    out[-1] = (out[-1][0], q0, 0, 0)
+                else:
+                    out.append((s, q0, 0, 0))
+            out.append((q0, q1, 1, 0))
+        else:
+            ivs = []
+            for i in range(i0, i1 + 1):
+                ivs.extend(plan.path_runs[i])
+                s, e = int(seg_off[i]), min(q1, int(seg_off[i + 1]))
+                if e > s:
+                    ivs.append((s, e))
+            ivs.sort()
+            cb, ce = ivs[0]
+            for b, e in ivs[1:]:
+                if b <= ce:
+                    ce = max(ce, e)
+                else:
+                    out.append((cb, ce, 1, 0)); cb, ce = b, e
+            out.append((cb, ce, 1, 0))
+        run_ptr.append(len(out))
+    return np.asarray(run_ptr, np.int32), np.asarray(out, np.int32).reshape(-1, 4)

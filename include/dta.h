@@ -1,0 +1,115 @@
+/*
+ * dta.h — C ABI of libdta_mi355x.so: the MI355X (gfx950) tree-attention hot path of DynamicTreeAttn.
+ *
+ * The reference (/root/reference, 17 Python files) has NO native code and therefore no FFI; these
+ * entry points are what a binding for its hot path would call.  Each one names the reference
+ * interface it replaces (file:line into /root/reference).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions: raw device pointers + sizes + a hipStream_t passed as void*;
+ * returns 0 on success, a negative DTA_E* code on invalid arguments (nothing is launched then);
+ * no allocation, no ownership transfer, no global state, re-entrant across streams.  All
+ * launches are asynchronous on `stream`.  Device code exists for gfx950 only.
+ *
+ * Packed-trie vocabulary: the T tokens of a trie are laid out in DFS pre-order of its leaves
+ * ("packed order"): leaf i contributes the segment of its tokens at depths [lcp[i-1], len[i]).
+ * For packed token s, subtree_end[s] is one past its last descendant, so
+ *     s is an ancestor-or-self of t   <=>   s <= t < subtree_end[s].
+ */
+#ifndef DTA_H
+#define DTA_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTA_OK 0
+#define DTA_EINVAL (-1)      /* null pointer / negative size / inconsistent sizes */
+#define DTA_EUNSUPPORTED (-2)/* head_dim != 128, dtype not bf16/f16, Hq % Hkv != 0 ...  */
+#define DTA_EALIGN (-3)      /* pointer or stride not 16-byte aligned */
+#define DTA_ELAUNCH (-4)     /* hipGetLastError() after the launch was not hipSuccess */
+
+#define DTA_BF16 0
+#define DTA_F16 1
+
+#define DTA_QTILE 128        /* query rows per workgroup (fwd / dQ kernels)  */
+#define DTA_KTILE 128        /* key rows per workgroup (dK/dV kernel)        */
+
+int dta_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Trie build kernels (integer, bit-exact, HBM-bound)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Adjacent longest-common-prefix of S sequences stored back to back in `tokens` (int64) with
+ * `offsets[S+1]`; out_lcp[i] = lcp(seq i, seq i+1); *out_unsorted = number of adjacent pairs that
+ * violate lexicographic order (seq_i[lcp] > seq_{i+1}[lcp]).  The caller zeroes out_unsorted.
+ * Replaces token_trie.py:6-10 (_lcp_torch) and the order check token_trie.py:24-30.  */
+int dta_lcp_adjacent(const int64_t* tokens, const int64_t* offsets, int32_t S,
+                     int32_t* out_lcp, int32_t* out_unsorted, void* stream);
+
+/* Leafization as a stream compaction over the S sorted sequences: keep[i] = (i == S-1) ||
+ * lcp[i] < min(len[i], len[i+1]).  Writes the kept positions (ascending) to out_leaf_pos, the
+ * leaf's LCP with the next leaf to out_leaf_lcp, for every sequence the leaf it folds onto to
+ * out_seq_leaf[S], and the leaf count to *out_M.  One workgroup (S <= 2^20).
+ * Replaces token_trie.py:32-49 (_leafization, second half).  */
+int dta_leafize(const int64_t* offsets, const int32_t* lcp, int32_t S,
+                int32_t* out_leaf_pos, int32_t* out_leaf_lcp, int32_t* out_seq_leaf, int32_t* out_M,
+                void* stream);
+
+/* Packed pre-order metadata for M leaves visited in the given DFS order.  Inputs per leaf i:
+ * seg_off[i] (packed offset of its segment; seg_off[M] = T), seg_depth0[i] = lcp[i-1] (0 for i=0),
+ * leaf_tok_off[i] = offset of the leaf's tokens in `tokens`; and the per-segment "closing" table
+ * brk_ptr[M+1], brk_depth[], brk_end[]: tokens of segment i at depth d in
+ * [brk_depth[j], brk_depth[j+1]) have subtree_end = brk_end[j].  parent_of_seg[i] = packed index of
+ * the token at depth seg_depth0[i]-1 on leaf i's path (-1 when seg_depth0[i] == 0).
+ * Outputs per packed token: token id, depth (= RoPE position, the stack position of
+ * tree_training_engine.py:166,293), parent index, subtree_end.
+ * Replaces the per-leaf H2D copy + stack bookkeeping of tree_training_engine.py:536-548, 582-611. */
+int dta_preorder_meta(const int64_t* tokens, const int64_t* leaf_tok_off,
+                      const int32_t* seg_off, const int32_t* seg_depth0, const int32_t* parent_of_seg,
+                      const int32_t* brk_ptr, const int32_t* brk_depth, const int32_t* brk_end,
+                      int32_t M, int32_t T,
+                      int64_t* out_token, int32_t* out_depth, int32_t* out_parent, int32_t* out_subtree_end,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Tree attention (MFMA-bound).  head_dim must be 128; dtype DTA_BF16 or DTA_F16.
+ *
+ * q/out/dout/dq: [Tq, Hq, 128] with element strides (q_stride_t, 128); k/v/dk/dv: [Tk, Hkv, 128]
+ * with (kv_stride_t, 128).  Query row i has packed index q_offset + i.  It attends key s iff
+ * s <= q_offset+i  &&  q_offset+i < subtree_end[s]   (subtree_end == NULL: no upper bound, i.e. the
+ * rectangular-causal stack form of tree_training_engine.py:171-186 with q_offset = start).
+ *
+ * Query tiles are DTA_QTILE rows.  Tile j visits the key runs runs[run_ptr[j] .. run_ptr[j+1]),
+ * each run = 4 int32 {key_begin, key_end, needs_mask, 0}; runs == NULL: one run [0, last row + 1).
+ * A run with needs_mask == 0 promises that every key in it is visible to every row of the tile.
+ * lse: [Tq, Hq] float, log2-domain log-sum-exp of the scaled scores (natural lse = lse * ln 2).
+ * Replaces the attention the reference reaches through the model call,
+ * tree_training_engine.py:182-186, 248-252, 351-353 (third-party attention backend).  */
+int dta_tree_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+                      const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
+                      int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                      int64_t q_stride_t, int64_t kv_stride_t, int64_t o_stride_t,
+                      float scale, int32_t dtype, void* stream);
+
+/* Backward.  Two launches on `stream`: (1) per query tile: delta = rowsum(dout*out), dq;
+ * (2) per key tile of DTA_KTILE keys: dk, dv summed over the query range
+ * [max(key0, q_offset), ktile_qend[tile]) and over the Hq/Hkv query heads of the group — no
+ * cross-workgroup reduction, no atomics, bitwise reproducible.  ktile_qend[j] = max subtree_end
+ * over the tile's keys (NULL: q_offset + Tq).  `accumulate` != 0 adds into dk/dv (the grad-KV
+ * stack of tree_training_engine.py:447-451) instead of overwriting.  delta: [Tq, Hq] float workspace.
+ * Replaces torch.autograd.backward through the attention backend, tree_training_engine.py:440.  */
+int dta_tree_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                      const float* lse, float* delta, void* dq, void* dk, void* dv,
+                      const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
+                      const int32_t* ktile_qend,
+                      int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                      int64_t q_stride_t, int64_t kv_stride_t, int64_t o_stride_t,
+                      int64_t dq_stride_t, int64_t dkv_stride_t,
+                      float scale, int32_t dtype, int32_t accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTA_H */
