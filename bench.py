@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py — tree-attn fwd+bwd tokens/s, Qwen3-0.6B bf16, synthetic tau2-16k-shaped tries.
+
+One *step* = one pass of the hot path over one batch: every rank takes one bin of the global batch
+(N_ranks tau2-shaped calls merged and partitioned by ``LB_by_DFS_and_TM``, as data_parallel.py does
+offline), builds its TokenTrie (HIP LCP/leafization), permutes it for backward, runs
+``TreeTrainingEngine.backward`` (HIP tree attention fwd+bwd inside the full model pass) and the
+ranks sum their parameter gradients with one RCCL all-reduce.  Timed sync-to-sync like run.py:90-108;
+metric = Σ original-sequence tokens / wall (run_all.py:156-159), MAX over ranks.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant
+attention kernel, HIP-event timed on the launch stream) and `cpu_baseline` (the oracle's
+restatement of the reference schedule timed on the host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+from dynamictreeattn_amd import data_parallel as dp
+from dynamictreeattn_amd import ops, synth
+from dynamictreeattn_amd.model import Qwen3TreeLM, make_config
+from dynamictreeattn_amd.token_trie import TokenTrie
+from dynamictreeattn_amd.tree_time_model import TreeTimeModel
+from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine
+
+PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16 peak, MI355X_MICROARCH.md "Chip-level parameters"
+ATTACH = {"w_logprobs": -1.0, "w_entropy": 0.1}      # run_all.py:11-14
+
+
+def loss_fn(logprob, entropy, attachment):            # run.py:149-152
+    return attachment["w_logprobs"] * logprob.mean() + attachment["w_entropy"] * entropy.mean()
+
+
+def build_model(cfg: dict, device, dtype, seed: int = 0):
+    m = Qwen3TreeLM(cfg).to(device=device, dtype=dtype)
+    g = torch.Generator(device=device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("norm.weight") or "layernorm" in name:
+                p.fill_(1.0)
+            else:
+                p.copy_((torch.randn(p.shape, generator=g, device=device, dtype=torch.float32) * 0.02).to(dtype))
+    return m.train()
+
+
+def allreduce_grads(model, bucket_elems: int = 1 << 28):
+    """One logical all-reduce(SUM) of every parameter gradient (no averaging: the reference's loss is
+    a plain sum over sequences, tte:396-398), in a few large flat buckets for RCCL over xGMI."""
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    i = 0
+    while i < len(grads):
+        chunk, n = [], 0
+        while i < len(grads) and (not chunk or n + grads[i].numel() <= bucket_elems):
+            chunk.append(grads[i]); n += grads[i].numel(); i += 1
+        flat = torch.cat([g.reshape(-1) for g in chunk])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        o = 0
+        for g in chunk:
+            g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
+
+
+def cpu_baseline(threads: int):
+    """The oracle's restatement of the reference push/pop schedule (tree_training_engine.py:555-616) on
+    the host cores, Qwen3-0.6B dims bf16, on a bounded tau2-shaped sample."""
+    import numpy as np
+    from oracle import model_oracle as mo
+    from oracle import trie_oracle as to
+    torch.set_num_threads(threads)
+    case = {"kind": "tau2", "seed": 0, "G": 2, "sys_len": 500, "turns": 3, "lo": 50, "hi": 225, "cap": 4096}
+    seqs = [np.asarray(s, dtype=np.int64) for s in synth.make_case(case)]
+    w = {k: v.requires_grad_(True) for k, v in mo.init_weights(mo.QWEN3_0P6B, seed=0, dtype=torch.bfloat16).items()}
+    t0 = time.time()
+    trie = to.TokenTrieOracle(seqs, [dict(ATTACH) for _ in seqs]); trie.backward_permute()
+    eng = mo.StackEngineOracle(mo.QWEN3_0P6B, w, max(len(s) for s in seqs), dtype=torch.bfloat16)
+    eng.backward(trie, mo.default_loss, 2048)
+    dt = time.time() - t0
+    st = trie.get_stats("backward", 2048)
+    return {"value": st["n_tokens"] / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"tau2-shaped call at 1/4 length scale (G=2, sys 500, 3 turns of 50-225): {st['n_sequences']} seqs, "
+                      f"{st['n_tokens']} tokens, {st['n_tree_tokens']} tree tokens, bf16, block_size 2048, {dt:.1f} s",
+            "tree_tokens_per_s": st["n_tree_tokens"] / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--block-size", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="qwen3-0.6b", choices=["qwen3-0.6b", "qwen3-4b"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    cfg = synth.QWEN3_0P6B if args.model == "qwen3-0.6b" else synth.QWEN3_4B
+    model = build_model(cfg, dev, torch.bfloat16)
+    engine = TreeTrainingEngine(make_config(cfg), dev, torch.bfloat16, max_seq_len=16384)     # run_all.py:86
+    V = cfg["vocab_size"]
+
+    # synthetic global batches, one per step: `world` tau2-shaped calls merged (CPU LongTensors, as the
+    # reference's .pt batches are)
+    total_steps = args.warmup + args.steps
+    batches = []
+    for s in range(total_steps):
+        seqs = []
+        for r in range(world):
+            seqs += synth.as_tensors(synth.tau2(seed=s * world + r, V=V))
+        batches.append(seqs)
+    bal_args = types.SimpleNamespace(K=world, mode="backward", block_size=args.block_size)
+
+    stats_acc = {"n_tokens": 0, "n_tree_tokens": 0, "pairs": 0}
+
+    def step(seqs, timed: bool):
+        if world > 1:
+            bins = dp.LB_by_DFS_and_TM(seqs, TreeTimeModel(), bal_args)
+            mine = [seqs[i] for i in bins[rank]]
+        else:
+            mine = seqs
+        model.zero_grad(set_to_none=True)
+        trie = TokenTrie(mine, [dict(ATTACH) for _ in mine])
+        trie.backward_permute()
+        loss = engine.backward(model, trie, loss_fn, args.block_size)
+        if world > 1:
+            allreduce_grads(model)
+        if timed:
+            st = trie.get_stats("backward", args.block_size)
+            stats_acc["n_tokens"] += st["n_tokens"]; stats_acc["n_tree_tokens"] += st["n_tree_tokens"]
+            stats_acc["pairs"] += st["sum_depth"] + st["n_tree_tokens"]
+        return loss
+
+    for s in range(args.warmup):
+        step(batches[s], False)
+        model.zero_grad(set_to_none=True)
+
+    timer = ops.KernelTimer()
+    ops.KernelTimer.active = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for s in range(args.warmup, total_steps):
+        step(batches[s], True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    ops.KernelTimer.active = None
+
+    tot = torch.tensor([wall, float(stats_acc["n_tokens"]), float(stats_acc["n_tree_tokens"])], device=dev, dtype=torch.float64)
+    if world > 1:
+        mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        wall, n_tokens, n_tree = float(mx[0]), float(sm[1]), float(sm[2])
+    else:
+        n_tokens, n_tree = float(tot[1]), float(tot[2])
+
+    # roofline of the dominant kernel (dK/dV): algorithmic FLOPs = 4 products x 2·Hq·D per visible pair
+    ms = timer.totals_ms()
+    L, Hq, D = cfg["num_hidden_layers"], cfg["num_attention_heads"], cfg["head_dim"]
+    pairs = stats_acc["pairs"]
+    def tf(coef, key):
+        t, n = ms[key]
+        return (coef * Hq * D * pairs * L) / (t * 1e-3) / 1e12 if t > 0 else 0.0, (t / n if n else 0.0)
+    dkv_tf, dkv_ms = tf(8, "bwd_dkv")
+    dq_tf, dq_ms = tf(2, "bwd_dq")
+    fwd_tf, fwd_ms = tf(4, "fwd")
+    attn_ms_total = ms["fwd"][0] + ms["bwd_dq"][0] + ms["bwd_dkv"][0]
+    all_tf = (14 * Hq * D * pairs * L) / (attn_ms_total * 1e-3) / 1e12 if attn_ms_total > 0 else 0.0
+
+    out = {
+        "metric": "tree-attn fwd+bwd tokens/sec, Qwen3-0.6B tau2-16k tries", "value": n_tokens / wall, "unit": "tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "tau2-16k-shaped trie batch (8 rollouts x 6 turns, 2000-token shared prompt, 48 seqs ~180k tokens "
+                               "per call), one call per GPU per step, Qwen3-0.6B random-init bf16, tree fwd+bwd, block_size 2048, permute=ours",
+                   "calls_per_step": world, "balancer": "LB_by_DFS_and_TM" if world > 1 else "none",
+                   "grad_allreduce": "RCCL sum" if world > 1 else "none"},
+        "tree_tokens_per_s": n_tree / wall,
+        "roofline": {"bound": "mfma", "kernel": "tree_attn_bwd_dkv_kernel", "achieved": dkv_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": dkv_tf / PEAK_BF16_TFLOPS, "traffic": None, "avg_launch_ms": dkv_ms,
+                     "flops_per_pair_per_layer": 8 * Hq * D, "pairs_per_step": pairs / max(args.steps, 1),
+                     "other_kernels": {"tree_attn_fwd_kernel": {"achieved": fwd_tf, "avg_launch_ms": fwd_ms, "flops_per_pair_per_layer": 4 * Hq * D},
+                                       "tree_attn_bwd_dq_kernel": {"achieved": dq_tf, "avg_launch_ms": dq_ms, "flops_per_pair_per_layer": 2 * Hq * D},
+                                       "attention_fwd+bwd_14HqD": {"achieved": all_tf, "ms_per_step": attn_ms_total / max(args.steps, 1)}}},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,13 +12,13 @@ _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 _PROTOS = {
     "dta_version": ([], C.c_int),
-    "dta_lcp_adjacent": ([_vp, _vp, _i32, _vp, _vp, _vp], C.c_int),
+    "dta_lcp_adjacent": ([_vp, _vp, _vp, _i32, _vp, _vp, _vp], C.c_int),
     "dta_leafize": ([_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp], C.c_int),
     "dta_preorder_meta": ([_vp] * 8 + [_i32, _i32] + [_vp] * 4 + [_vp], C.c_int),
     "dta_tree_attn_fwd": ([_vp] * 8 + [_i32] * 6 + [_i64] * 3 + [_f32, _i32, _vp], C.c_int),
     "dta_tree_attn_bwd": ([_vp] * 14 + [_i32] * 6 + [_i64] * 5 + [_f32, _i32, _i32, _vp], C.c_int),
     "dta_tree_attn_fwd_ex": ([_vp] * 8 + [_i32] * 6 + [_i64] * 6 + [_f32, _i32, _vp], C.c_int),
-    "dta_tree_attn_bwd_ex": ([_vp] * 14 + [_i32] * 6 + [_i64] * 10 + [_f32, _i32, _i32, _vp], C.c_int),
+    "dta_tree_attn_bwd_ex": ([_vp] * 14 + [_i32] * 6 + [_i64] * 10 + [_f32, _i32, _i32, _i32, _vp], C.c_int),
 }
 EXPORTS = tuple(_PROTOS)
 _ERR = {-1: "DTA_EINVAL", -2: "DTA_EUNSUPPORTED", -3: "DTA_EALIGN", -4: "DTA_ELAUNCH"}

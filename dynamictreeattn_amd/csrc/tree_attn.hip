@@ -535,7 +535,7 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
                                     int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
                                     int64_t q_st, int64_t q_sh, int64_t kv_st, int64_t kv_sh, int64_t o_st, int64_t o_sh,
                                     int64_t dq_st, int64_t dq_sh, int64_t dkv_st, int64_t dkv_sh,
-                                    float scale, int32_t dtype, int32_t accumulate, void* stream) {
+                                    float scale, int32_t dtype, int32_t accumulate, int32_t which, void* stream) {
   if (!q || !k || !v || !out || !dout || !lse || !delta || !dq || !dk || !dv || Tq <= 0 || Tk <= 0 || Hq <= 0 || Hkv <= 0 || q_offset < 0) return DTA_EINVAL;
   if ((runs == nullptr) != (run_ptr == nullptr)) return DTA_EINVAL;
   if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16)) return DTA_EUNSUPPORTED;
@@ -550,12 +550,13 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
   const int nkt = (Tk + DTA_KTILE - 1) / DTA_KTILE;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if ((which & 3) == 0) return DTA_EINVAL;
   if (dtype == DTA_BF16) {
-    hipLaunchKernelGGL(tree_attn_bwd_dq_kernel<DTA_BF16>, dim3(nqt * Hq), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_BF16>, dim3(nkt * Hkv), dim3(256), 0, st, p);
+    if (which & 1) hipLaunchKernelGGL(tree_attn_bwd_dq_kernel<DTA_BF16>, dim3(nqt * Hq), dim3(256), 0, st, p);
+    if (which & 2) hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_BF16>, dim3(nkt * Hkv), dim3(256), 0, st, p);
   } else {
-    hipLaunchKernelGGL(tree_attn_bwd_dq_kernel<DTA_F16>, dim3(nqt * Hq), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_F16>, dim3(nkt * Hkv), dim3(256), 0, st, p);
+    if (which & 1) hipLaunchKernelGGL(tree_attn_bwd_dq_kernel<DTA_F16>, dim3(nqt * Hq), dim3(256), 0, st, p);
+    if (which & 2) hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_F16>, dim3(nkt * Hkv), dim3(256), 0, st, p);
   }
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
 }
@@ -580,5 +581,5 @@ extern "C" int dta_tree_attn_bwd(const void* q, const void* k, const void* v, co
                                  float scale, int32_t dtype, int32_t accumulate, void* stream) {
   return dta_tree_attn_bwd_ex(q, k, v, out, dout, lse, delta, dq, dk, dv, subtree_end, run_ptr, runs, ktile_qend,
                               Tq, Tk, q_offset, Hq, Hkv, head_dim, q_stride_t, 128, kv_stride_t, 128, o_stride_t, 128,
-                              dq_stride_t, 128, dkv_stride_t, 128, scale, dtype, accumulate, stream);
+                              dq_stride_t, 128, dkv_stride_t, 128, scale, dtype, accumulate, 3, stream);
 }

@@ -11,14 +11,14 @@ namespace {
 // One 256-thread workgroup per adjacent pair.  Every step compares 1024 positions (4 coalesced
 // 8-byte loads per lane per sequence in flight), ballots the mismatches per wave and stops at the
 // first step that holds one.
-__global__ __launch_bounds__(256) void lcp_adjacent_kernel(const int64_t* __restrict__ tokens, const int64_t* __restrict__ offsets,
+__global__ __launch_bounds__(256) void lcp_adjacent_kernel(const int64_t* __restrict__ tokens, const int64_t* __restrict__ starts,
+                                                           const int32_t* __restrict__ lens,
                                                            int32_t S, int32_t* __restrict__ out_lcp, int32_t* __restrict__ out_unsorted) {
   __shared__ int first_bad;
   const int pair = blockIdx.x;
   if (pair >= S - 1) return;
-  const int64_t oa = offsets[pair], ob = offsets[pair + 1], oc = offsets[pair + 2];
-  const int64_t* a = tokens + oa; const int64_t* b = tokens + ob;
-  const int la = (int)(ob - oa), lb = (int)(oc - ob);
+  const int64_t* a = tokens + starts[pair]; const int64_t* b = tokens + starts[pair + 1];
+  const int la = lens[pair], lb = lens[pair + 1];
   const int n = la < lb ? la : lb;
   const int tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) first_bad = n;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void lcp_adjacent_kernel(const int64_t* __rest
 }
 
 // Single workgroup of 1024 threads; chunks of 1024 sequences with a running base.
-__global__ __launch_bounds__(1024) void leafize_kernel(const int64_t* __restrict__ offsets, const int32_t* __restrict__ lcp, int32_t S,
+__global__ __launch_bounds__(1024) void leafize_kernel(const int32_t* __restrict__ lens, const int32_t* __restrict__ lcp, int32_t S,
                                                        int32_t* __restrict__ leaf_pos, int32_t* __restrict__ leaf_lcp,
                                                        int32_t* __restrict__ seq_leaf, int32_t* __restrict__ out_M) {
   __shared__ int wave_cnt[16];
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(1024) void leafize_kernel(const int64_t* __restrict
     if (i < S) {
       if (i == S - 1) keep = true;
       else {
-        const int li = (int)(offsets[i + 1] - offsets[i]), lj = (int)(offsets[i + 2] - offsets[i + 1]);
+        const int li = lens[i], lj = lens[i + 1];
         keep = lcp[i] < (li < lj ? li : lj);
       }
     }
@@ -108,19 +108,19 @@ __global__ __launch_bounds__(256) void preorder_meta_kernel(const int64_t* __res
 
 extern "C" int dta_version(void) { return 100; }
 
-extern "C" int dta_lcp_adjacent(const int64_t* tokens, const int64_t* offsets, int32_t S,
+extern "C" int dta_lcp_adjacent(const int64_t* tokens, const int64_t* starts, const int32_t* lens, int32_t S,
                                 int32_t* out_lcp, int32_t* out_unsorted, void* stream) {
-  if (!tokens || !offsets || !out_unsorted || S < 1 || (S > 1 && !out_lcp)) return DTA_EINVAL;
+  if (!tokens || !starts || !lens || !out_unsorted || S < 1 || (S > 1 && !out_lcp)) return DTA_EINVAL;
   if (S == 1) return DTA_OK;
-  hipLaunchKernelGGL(lcp_adjacent_kernel, dim3(S - 1), dim3(256), 0, static_cast<hipStream_t>(stream), tokens, offsets, S, out_lcp, out_unsorted);
+  hipLaunchKernelGGL(lcp_adjacent_kernel, dim3(S - 1), dim3(256), 0, static_cast<hipStream_t>(stream), tokens, starts, lens, S, out_lcp, out_unsorted);
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
 }
 
-extern "C" int dta_leafize(const int64_t* offsets, const int32_t* lcp, int32_t S,
+extern "C" int dta_leafize(const int32_t* lens, const int32_t* lcp, int32_t S,
                            int32_t* out_leaf_pos, int32_t* out_leaf_lcp, int32_t* out_seq_leaf, int32_t* out_M, void* stream) {
-  if (!offsets || !out_leaf_pos || !out_leaf_lcp || !out_seq_leaf || !out_M || S < 1 || (S > 1 && !lcp)) return DTA_EINVAL;
+  if (!lens || !out_leaf_pos || !out_leaf_lcp || !out_seq_leaf || !out_M || S < 1 || (S > 1 && !lcp)) return DTA_EINVAL;
   if (S > (1 << 20)) return DTA_EUNSUPPORTED;
-  hipLaunchKernelGGL(leafize_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), offsets, lcp, S, out_leaf_pos, out_leaf_lcp, out_seq_leaf, out_M);
+  hipLaunchKernelGGL(leafize_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), lens, lcp, S, out_leaf_pos, out_leaf_lcp, out_seq_leaf, out_M);
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
 }
 

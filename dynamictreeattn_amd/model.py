@@ -1,0 +1,169 @@
+"""Qwen3-family decoder over a *packed trie* (one pass over all tree tokens).
+
+The reference drives an unmodified HuggingFace causal LM once per trie segment
+(tree_training_engine.py:182-186, 248-252, 351-353).  Here the whole trie is one batch of T packed
+tokens: position = trie depth, attention = `ops.tree_attention` (HIP), GEMMs = hipBLASLt through
+torch.  `Qwen3TreeLM` mirrors the HF module/parameter tree (``model.embed_tokens.weight``,
+``model.layers.N.self_attn.q_proj.weight`` …, tied head) so that
+
+* gradients compare name by name with grad/Qwen3-0.6B-TB-vs-DB-bf16.txt (310 tensors), and
+* `packed_hidden_states` also accepts a HuggingFace Qwen2/Qwen3 ``*ForCausalLM`` by duck typing —
+  its own ``nn.Parameter`` objects are used, so ``param.grad`` lands where the training loop expects.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class _Norm(nn.Module):
+    def __init__(self, n):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n))
+
+
+class _Lin(nn.Module):
+    def __init__(self, i, o):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(o, i))
+
+
+class _Attn(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        H, Hq, Hkv, D = c.hidden_size, c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        self.q_proj, self.k_proj, self.v_proj, self.o_proj = _Lin(H, Hq * D), _Lin(H, Hkv * D), _Lin(H, Hkv * D), _Lin(Hq * D, H)
+        self.q_norm, self.k_norm = _Norm(D), _Norm(D)
+
+
+class _MLP(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.gate_proj, self.up_proj, self.down_proj = _Lin(c.hidden_size, c.intermediate_size), _Lin(c.hidden_size, c.intermediate_size), _Lin(c.intermediate_size, c.hidden_size)
+
+
+class _Layer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.self_attn, self.mlp = _Attn(c), _MLP(c)
+        self.input_layernorm, self.post_attention_layernorm = _Norm(c.hidden_size), _Norm(c.hidden_size)
+
+
+class _Body(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(c.vocab_size, c.hidden_size)
+        self.layers = nn.ModuleList(_Layer(c) for _ in range(c.num_hidden_layers))
+        self.norm = _Norm(c.hidden_size)
+
+
+def make_config(d: dict) -> SimpleNamespace:
+    c = SimpleNamespace(**d)
+    if not hasattr(c, "head_dim"):
+        c.head_dim = c.hidden_size // c.num_attention_heads
+    c.rms_norm_eps = getattr(c, "rms_norm_eps", 1e-6)
+    c.rope_theta = getattr(c, "rope_theta", 1e6)
+    return c
+
+
+class Qwen3TreeLM(nn.Module):
+    """Parameter container with the HF names; tied LM head (no lm_head parameter)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = make_config(config) if isinstance(config, dict) else config
+        self.model = _Body(self.config)
+
+    @property
+    def device(self):
+        return self.model.embed_tokens.weight.device
+
+    @torch.no_grad()
+    def load_named(self, weights: dict):
+        own = dict(self.named_parameters())
+        for k, p in own.items():
+            p.copy_(weights[k])
+        return self
+
+    @classmethod
+    def from_named(cls, config, weights: dict, device, dtype):
+        m = cls(config)
+        m.load_named(weights)
+        return m.to(device=device, dtype=dtype)
+
+
+def _cfg_of(model):
+    c = model.config
+    D = getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads
+    theta = getattr(c, "rope_theta", None)
+    if theta is None:
+        rp = getattr(c, "rope_parameters", None) or {}
+        theta = rp.get("rope_theta", 1e6) if isinstance(rp, dict) else 1e6
+    return c.num_attention_heads, c.num_key_value_heads, D, float(getattr(c, "rms_norm_eps", 1e-6)), float(theta)
+
+
+def _rms(x, w, eps):
+    # same arithmetic as the reference's model: normalise in fp32, round to the model dtype, then scale
+    xf = x.float()
+    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return w * xf.to(x.dtype)
+
+
+def rope_tables(depth: torch.Tensor, D: int, theta: float, dtype):
+    inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.float32, device=depth.device) / D))
+    ang = depth.float()[:, None] * inv[None, :]
+    ang = torch.cat([ang, ang], dim=-1)
+    return ang.cos().to(dtype)[:, None, :], ang.sin().to(dtype)[:, None, :]
+
+
+def _rot(x, cos, sin):
+    h = x.shape[-1] // 2
+    return x * cos + torch.cat([-x[..., h:], x[..., :h]], dim=-1) * sin
+
+
+def _layer_forward(layer, x, cos, sin, meta, Hq, Hkv, D, eps, attn_fn):
+    T = x.shape[0]
+    a = layer.self_attn
+    h = _rms(x, layer.input_layernorm.weight, eps)
+    q = F.linear(h, a.q_proj.weight, getattr(a.q_proj, "bias", None)).view(T, Hq, D)
+    k = F.linear(h, a.k_proj.weight, getattr(a.k_proj, "bias", None)).view(T, Hkv, D)
+    v = F.linear(h, a.v_proj.weight, getattr(a.v_proj, "bias", None)).view(T, Hkv, D)
+    if hasattr(a, "q_norm"):
+        q = _rms(q, a.q_norm.weight, eps); k = _rms(k, a.k_norm.weight, eps)
+    q = _rot(q, cos, sin); k = _rot(k, cos, sin)
+    o = attn_fn(q, k, v, meta)
+    x = x + F.linear(o.reshape(T, Hq * D), a.o_proj.weight)
+    h = _rms(x, layer.post_attention_layernorm.weight, eps)
+    m = layer.mlp
+    x = x + F.linear(F.silu(F.linear(h, m.gate_proj.weight)) * F.linear(h, m.up_proj.weight), m.down_proj.weight)
+    return x
+
+
+def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta, checkpoint_layers: bool = False,
+                         attn_fn=None) -> torch.Tensor:
+    """Final-norm hidden states [T, hidden] of the packed tokens.  `model` is a Qwen3TreeLM or an HF
+    Qwen2/Qwen3 *ForCausalLM (duck-typed).  `attn_fn(q,k,v,meta)` defaults to the HIP operator."""
+    attn_fn = attn_fn or ops.tree_attention
+    Hq, Hkv, D, eps, theta = _cfg_of(model)
+    body = model.model
+    x = F.embedding(tokens, body.embed_tokens.weight)
+    cos, sin = rope_tables(depth, D, theta, x.dtype)
+    for layer in body.layers:
+        if checkpoint_layers and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+            x = checkpoint(_layer_forward, layer, x, cos, sin, meta, Hq, Hkv, D, eps, attn_fn, use_reentrant=False)
+        else:
+            x = _layer_forward(layer, x, cos, sin, meta, Hq, Hkv, D, eps, attn_fn)
+    return _rms(x, body.norm.weight, eps)
+
+
+def head_weight(model) -> torch.Tensor:
+    lm = getattr(model, "lm_head", None)
+    return lm.weight if lm is not None else model.model.embed_tokens.weight

@@ -18,6 +18,24 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional live timing of the attention launches with HIP events recorded on the launch stream
+    (bench.py's roofline leg).  Disabled unless `KernelTimer.active` is set to an instance."""
+    active: Optional["KernelTimer"] = None
+
+    def __init__(self):
+        self.spans = {"fwd": [], "bwd_dq": [], "bwd_dkv": []}
+
+    def span(self, name):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.spans[name].append((a, b))
+        return a, b
+
+    def totals_ms(self):
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.spans.items()}
+
+
 def _require_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -59,8 +77,13 @@ def attn_fwd_raw(q, k, v, meta: TreeAttnMeta, scale: float):
     out = torch.empty((Tq, Hq, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((Tq, Hq), dtype=torch.float32, device=q.device)
     (qs, qh), (ks, kh), (os_, oh) = _strides(q), _strides(k), _strides(out)
+    tm = KernelTimer.active
+    if tm is not None:
+        ev = tm.span("fwd"); ev[0].record()
     st = lib().dta_tree_attn_fwd_ex(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(meta.subtree_end), ptr(meta.run_ptr), ptr(meta.runs),
                                     Tq, Tk, meta.q_offset, Hq, Hkv, D, qs, qh, ks, kh, os_, oh, float(scale), _DT[q.dtype], _stream())
+    if tm is not None:
+        ev[1].record()
     check(st, "dta_tree_attn_fwd")
     return out, lse, k, v
 
@@ -68,19 +91,25 @@ def attn_fwd_raw(q, k, v, meta: TreeAttnMeta, scale: float):
 def attn_bwd_raw(q, k, v, out, dout, lse, meta: TreeAttnMeta, scale: float, dk=None, dv=None, accumulate=False):
     Tq, Hq, D = q.shape
     Tk, Hkv, _ = k.shape
-    dout = dout if (dout.stride(-1) == 1 and dout.stride() == out.stride()) else dout.contiguous().view_as(out) if False else dout.contiguous()
     if dout.stride() != out.stride():
-        out = out.contiguous()
+        dout = dout.contiguous(); out = out.contiguous()
     dq = torch.empty((Tq, Hq, D), dtype=q.dtype, device=q.device)
     if dk is None:
         dk = torch.empty((Tk, Hkv, D), dtype=q.dtype, device=q.device); dv = torch.empty_like(dk)
     delta = torch.empty((Tq, Hq), dtype=torch.float32, device=q.device)
     (qs, qh), (ks, kh), (os_, oh), (dqs, dqh), (dks, dkh) = _strides(q), _strides(k), _strides(out), _strides(dq), _strides(dk)
-    st = lib().dta_tree_attn_bwd_ex(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-                                    ptr(meta.subtree_end), ptr(meta.run_ptr), ptr(meta.runs), ptr(meta.ktile_qend),
-                                    Tq, Tk, meta.q_offset, Hq, Hkv, D, qs, qh, ks, kh, os_, oh, dqs, dqh, dks, dkh,
-                                    float(scale), _DT[q.dtype], 1 if accumulate else 0, _stream())
-    check(st, "dta_tree_attn_bwd")
+    def launch(which):
+        return lib().dta_tree_attn_bwd_ex(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                                          ptr(meta.subtree_end), ptr(meta.run_ptr), ptr(meta.runs), ptr(meta.ktile_qend),
+                                          Tq, Tk, meta.q_offset, Hq, Hkv, D, qs, qh, ks, kh, os_, oh, dqs, dqh, dks, dkh,
+                                          float(scale), _DT[q.dtype], 1 if accumulate else 0, which, _stream())
+    tm = KernelTimer.active
+    if tm is None:
+        check(launch(3), "dta_tree_attn_bwd")
+    else:
+        for which, name in ((1, "bwd_dq"), (2, "bwd_dkv")):
+            a, b = tm.span(name); a.record(); st = launch(which); b.record()
+            check(st, "dta_tree_attn_bwd")
     return dq, dk, dv
 
 

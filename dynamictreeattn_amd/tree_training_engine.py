@@ -1,0 +1,231 @@
+"""TreeTrainingEngine — drop-in for the reference's engine (tree_training_engine.py:52-616), new
+mechanism.
+
+The reference walks the trie leaf by leaf over a stack-shaped KV cache: one model call per pushed
+segment, and per popped block a re-forward + ``autograd.backward`` with K/V-, logprob-, entropy- and
+fork-logit-gradients injected by hand (tte:315-487).  On a 288 GB MI355X the whole trie fits in one
+pass, so this engine
+
+1. lays all tree tokens out in DFS pre-order of the (already permuted) leaves — HIP kernel
+   ``dta_preorder_meta`` gathers token ids and writes depth / parent / subtree_end per token from
+   O(M·height) host tables (packing.py);
+2. runs the decoder ONCE over the T packed tokens with position = depth and the HIP tree-attention
+   operator (ancestor visibility  s <= t < subtree_end[s]);
+3. takes logprob(token | parent) and entropy(node) for every tree node, gathers them along each
+   leaf's root path, applies the user's ``loss_fn`` per original sequence exactly as tte:379-398 does
+   (``logprobs[:len-1]``, ``entropy[:len]``, attachment) and calls ``backward()`` once.
+
+Same results (sum-of-sequence losses, parameter gradients), none of the side channels
+(``grad_kv``, ``grad_logprobs``, ``grad_entropy``, fork logits), no per-segment host syncs.
+``block_size`` keeps its meaning as the memory knob: it is the row-chunk of the LM-head/logprob
+stage (the [rows, V] logits are never materialised beyond one chunk); ``cut_f1_tail`` has nothing
+left to cut (no token is forwarded twice) and is accepted for signature parity.
+"""
+from __future__ import annotations
+
+from math import ceil
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops, packing
+from .model import head_weight, packed_hidden_states
+from .trie import pop_block_starts
+
+__all__ = ["TreeTrainingEngine", "_get_forkpos", "packed_logprob_entropy"]
+
+
+def _get_forkpos(lens, lcp_lens, block_size: Optional[int]) -> list:
+    """Sorted unique stack positions whose logits the reference engine must keep: branch points
+    (lcp-1) and block boundaries (block start-1).  tree_training_engine.py:12-49.  The packed engine
+    does not need them; kept as part of the public surface (stats / tooling)."""
+    pos = {c - 1 for c in lcp_lens if c > 0}
+    if block_size is not None:
+        for i, end in enumerate(lens):
+            start = lcp_lens[i] if i < len(lcp_lens) else 0
+            pos.update(s - 1 for s in pop_block_starts(start, end, block_size) if s > 0)
+    return sorted(pos)
+
+
+# --------------------------------------------------------------------------------------------------
+# LM head + logprob/entropy over packed rows
+# --------------------------------------------------------------------------------------------------
+def _head_chunk(h_rows, W, next_tok, fork_rows, fork_tok, want_entropy: bool):
+    logits = torch.nn.functional.linear(h_rows, W)
+    lp_all = torch.log_softmax(logits.float(), dim=-1)
+    ent = -(lp_all.exp() * lp_all).sum(-1) if want_entropy else lp_all.new_zeros(())
+    lp_next = lp_all.gather(-1, next_tok[:, None]).squeeze(-1)
+    lp_fork = lp_all[fork_rows, fork_tok] if fork_rows.numel() else lp_all.new_zeros(0)
+    return lp_next, lp_fork, ent
+
+
+def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tensor, parent: torch.Tensor,
+                           want_entropy: bool, chunk: int = 2048, fork_child: Optional[np.ndarray] = None,
+                           fork_parent: Optional[np.ndarray] = None):
+    """lp[t] = log softmax(h[parent[t]] Wᵀ)[tokens[t]] (0 for roots), ent[t] = H(softmax(h[t] Wᵀ)); fp32.
+    Rows are processed `chunk` at a time and recomputed in backward, so at most one [chunk, V] block
+    of logits is alive (vocab_parallel.py:13-27 arithmetic; tte:190-193, 256-261, 361-372 call sites).
+    `fork_child`/`fork_parent`: host lists of the tokens whose parent is not the preceding packed token."""
+    from torch.utils.checkpoint import checkpoint
+    T = h.shape[0]
+    dev = h.device
+    if fork_child is None:
+        fork_child = np.zeros(0, np.int64); fork_parent = np.zeros(0, np.int64)
+    order = np.argsort(fork_parent, kind="stable")
+    fork_child, fork_parent = np.asarray(fork_child, np.int64)[order], np.asarray(fork_parent, np.int64)[order]
+    fc_dev = torch.from_numpy(fork_child).to(dev)
+    fp_dev = torch.from_numpy(fork_parent).to(dev)
+    ftok = tokens[fc_dev] if fork_child.size else tokens.new_zeros(0)
+    nxt = torch.cat([tokens[1:], tokens.new_zeros(1)])
+    lp_next_parts, ent_parts, lp_fork_parts = [], [], []
+    for a in range(0, T, chunk):
+        b = min(a + chunk, T)
+        f0, f1 = np.searchsorted(fork_parent, [a, b])
+        args = (h[a:b], W, nxt[a:b], fp_dev[f0:f1] - a, ftok[f0:f1], want_entropy)
+        if torch.is_grad_enabled() and h.requires_grad:
+            lp_next, lp_fork, ent = checkpoint(_head_chunk, *args, use_reentrant=False)
+        else:
+            lp_next, lp_fork, ent = _head_chunk(*args)
+        lp_next_parts.append(lp_next); lp_fork_parts.append(lp_fork)
+        if want_entropy:
+            ent_parts.append(ent)
+    lp_next = torch.cat(lp_next_parts)                       # lp_next[r] = log p(tokens[r+1] | node r)
+    chain = torch.zeros(T, dtype=torch.bool, device=dev)
+    chain[1:] = parent[1:] == torch.arange(0, T - 1, device=dev, dtype=parent.dtype)
+    lp = torch.cat([lp_next.new_zeros(1), lp_next[:-1]]) * chain
+    if fork_child.size:
+        lp = lp.index_copy(0, fc_dev, torch.cat(lp_fork_parts))
+    return lp, (torch.cat(ent_parts) if want_entropy else None)
+
+
+# --------------------------------------------------------------------------------------------------
+class _PackedTrie:
+    """Device-resident packed form of a TokenTrie (in its current leaf order)."""
+
+    def __init__(self, trie, device):
+        self.plan = plan = packing.plan_segments(trie.lens, trie.lcp_lens)
+        M, T = plan.M, plan.T
+        run_ptr, runs = packing.plan_qtile_runs(plan)
+        leaf_off = np.asarray([trie._dev.starts[s] for s in trie._leaf_src], np.int64)
+        parts = [plan.seg_off, plan.seg_depth0, plan.parent_of_seg, plan.brk_ptr, plan.brk_depth, plan.brk_end,
+                 run_ptr, runs.reshape(-1)]
+        sizes = [p.size for p in parts]
+        pad = [(-s) % 4 for s in sizes]                      # keep every slice 16-byte aligned
+        flat = np.concatenate([np.concatenate([p.astype(np.int32, copy=False), np.zeros(z, np.int32)]) for p, z in zip(parts, pad)])
+        buf = torch.from_numpy(flat).to(device, non_blocking=True)
+        views, o = [], 0
+        for s, z in zip(sizes, pad):
+            views.append(buf[o:o + s]); o += s + z
+        seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, run_ptr_d, runs_d = views
+        leaf_off_d = torch.from_numpy(leaf_off).to(device, non_blocking=True)
+        self.tokens = torch.empty(T, dtype=torch.long, device=device)
+        meta_i = torch.empty(3, T, dtype=torch.int32, device=device)
+        self.depth, self.parent, self.subtree_end = meta_i[0], meta_i[1], meta_i[2]
+        self._expand(trie._dev.tokens, leaf_off_d, seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, M, T)
+        self.meta = ops.TreeAttnMeta(T=T, subtree_end=self.subtree_end, run_ptr=run_ptr_d, runs=runs_d.view(-1, 4),
+                                     ktile_qend=ops.ktile_qend_from(self.subtree_end))
+        first = plan.seg_off[:-1].astype(np.int64)
+        nonempty = np.diff(plan.seg_off) > 0
+        par = plan.parent_of_seg.astype(np.int64)
+        is_fork = nonempty & (par >= 0) & (par != first - 1)
+        self.fork_child, self.fork_parent = first[is_fork], par[is_fork]
+        # root path of every leaf as packed indices (depth 0 .. len-1)
+        paths = []
+        for i in range(M):
+            pieces = [np.arange(b, e, dtype=np.int64) for b, e in plan.path_runs[i]]
+            pieces.append(np.arange(plan.seg_off[i], plan.seg_off[i + 1], dtype=np.int64))
+            paths.append(np.concatenate(pieces))
+        cat = torch.from_numpy(np.concatenate(paths)).to(device, non_blocking=True)
+        self.paths = list(torch.split(cat, [p.size for p in paths]))
+
+    def _expand(self, tokens, leaf_off, seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, M, T):
+        from ._lib import check, lib, ptr
+        st = lib().dta_preorder_meta(ptr(tokens), ptr(leaf_off), ptr(seg_off), ptr(seg_d0), ptr(par_seg), ptr(brk_ptr), ptr(brk_depth),
+                                     ptr(brk_end), M, T, ptr(self.tokens), ptr(self.depth), ptr(self.parent), ptr(self.subtree_end),
+                                     torch.cuda.current_stream().cuda_stream)
+        check(st, "dta_preorder_meta")
+
+
+class TreeTrainingEngine:
+    def __init__(self, model_config, device, dtype: torch.dtype, max_seq_len: int, forward_only: bool = False):
+        self.model = None
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.max_seq_len = max_seq_len
+        self.forward_only = forward_only
+        self.n_layers = model_config.num_hidden_layers
+        self.cur_len = 0                      # the packed engine is stateless between calls (reference: tte:550, 614-615)
+        self.forkpos_list: List[int] = []
+        self.returns: List[Optional[torch.Tensor]] = []
+        self.last_packed: Optional[_PackedTrie] = None
+        self.head_chunk = 2048
+        self.checkpoint_layers: Optional[bool] = None    # None = decide from free HBM
+
+    # ------------------------------------------------------------------------------------------
+    def _pack(self, token_trie) -> _PackedTrie:
+        longest = max(token_trie.lens) if token_trie.lens else 0
+        assert longest <= self.max_seq_len, (                                   # tte:162-164, 289-291
+            f"Exceeds max_seq_len: cur_len=0, new_tokens={longest}, max={self.max_seq_len}")
+        packed = _PackedTrie(token_trie, self.device)
+        self.last_packed = packed
+        return packed
+
+    def _should_checkpoint(self, model, T: int) -> bool:
+        if self.checkpoint_layers is not None:
+            return self.checkpoint_layers
+        c = model.config
+        D = getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads
+        per_tok = 2 * (10 * c.hidden_size + 4 * c.intermediate_size + 4 * (c.num_attention_heads + c.num_key_value_heads) * D)
+        need = per_tok * self.n_layers * T
+        if self.device.type != "cuda":
+            return False
+        free, _ = torch.cuda.mem_get_info(self.device)
+        return need > 0.6 * free
+
+    def _path_losses(self, packed, token_trie, lp, ent, loss_fn):
+        total = None
+        for i, attach_list in enumerate(token_trie.attach_lists):
+            idx = packed.paths[i]
+            lp_path = lp[idx[1:]]
+            ent_path = ent[idx]
+            for attachment, length in attach_list:                              # tte:379-398
+                term = loss_fn(lp_path[:length - 1], ent_path[:length], attachment)
+                total = term if total is None else total + term
+        return total
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, model, token_trie) -> List[torch.Tensor]:
+        """Per-sequence logprobs ``[len_i - 1]`` (fp32), indexed by original sequence id (tte:515-553)."""
+        self.model = model
+        self.returns = [None] * token_trie.n_sequences
+        self.forkpos_list = _get_forkpos(None, token_trie.lcp_lens, None)
+        packed = self._pack(token_trie)
+        h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, False)
+        lp, _ = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, False, self.head_chunk,
+                                       packed.fork_child, packed.fork_parent)
+        for i, attach_list in enumerate(token_trie.attach_lists):
+            lp_path = lp[packed.paths[i][1:]]
+            for attachment, length in attach_list:
+                self.returns[attachment["_sequence_batch_id"]] = lp_path[:length - 1].clone()
+        self.cur_len = 0
+        return self.returns
+
+    def backward(self, model, token_trie, loss_fn: Callable, block_size: int, cut_f1_tail: bool = True) -> float:
+        """Accumulates d(sum of per-sequence losses)/d(params) into ``param.grad``; returns the loss sum
+        (tte:555-616)."""
+        self.model = model
+        lens = [int(ids.size(0)) for ids in token_trie.inputs]
+        self.forkpos_list = _get_forkpos(lens, token_trie.lcp_lens, block_size)
+        packed = self._pack(token_trie)
+        chunk = min(self.head_chunk, block_size) if block_size else self.head_chunk
+        h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, self._should_checkpoint(model, packed.plan.T))
+        lp, ent = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, True, max(chunk, 1),
+                                         packed.fork_child, packed.fork_parent)
+        total = self._path_losses(packed, token_trie, lp, ent, loss_fn)
+        if total is None:
+            return 0.0
+        total.backward()
+        self.cur_len = 0
+        return float(total.item())

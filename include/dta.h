@@ -41,19 +41,21 @@ int dta_version(void);
  * Trie build kernels (integer, bit-exact, HBM-bound)
  * ------------------------------------------------------------------------------------------- */
 
-/* Adjacent longest-common-prefix of S sequences stored back to back in `tokens` (int64) with
- * `offsets[S+1]`; out_lcp[i] = lcp(seq i, seq i+1); *out_unsorted = number of adjacent pairs that
- * violate lexicographic order (seq_i[lcp] > seq_{i+1}[lcp]).  The caller zeroes out_unsorted.
- * Replaces token_trie.py:6-10 (_lcp_torch) and the order check token_trie.py:24-30.  */
-int dta_lcp_adjacent(const int64_t* tokens, const int64_t* offsets, int32_t S,
+/* Adjacent longest-common-prefix of S sequences held in one int64 `tokens` buffer: sequence i (in
+ * the order to be compared) is tokens[starts[i] .. starts[i]+lens[i]).  out_lcp[i] = lcp(seq i,
+ * seq i+1); *out_unsorted += number of adjacent pairs that violate lexicographic order
+ * (seq_i[lcp] > seq_{i+1}[lcp]).  The caller zeroes out_unsorted.
+ * Replaces token_trie.py:6-10 (_lcp_torch), the order check token_trie.py:24-30 and the
+ * recomputation after a permutation, token_trie.py:94.  */
+int dta_lcp_adjacent(const int64_t* tokens, const int64_t* starts, const int32_t* lens, int32_t S,
                      int32_t* out_lcp, int32_t* out_unsorted, void* stream);
 
 /* Leafization as a stream compaction over the S sorted sequences: keep[i] = (i == S-1) ||
  * lcp[i] < min(len[i], len[i+1]).  Writes the kept positions (ascending) to out_leaf_pos, the
  * leaf's LCP with the next leaf to out_leaf_lcp, for every sequence the leaf it folds onto to
- * out_seq_leaf[S], and the leaf count to *out_M.  One workgroup (S <= 2^20).
+ * out_seq_leaf[S] (lens[S] = sequence lengths in sorted order), and the leaf count to *out_M.  One workgroup (S <= 2^20).
  * Replaces token_trie.py:32-49 (_leafization, second half).  */
-int dta_leafize(const int64_t* offsets, const int32_t* lcp, int32_t S,
+int dta_leafize(const int32_t* lens, const int32_t* lcp, int32_t S,
                 int32_t* out_leaf_pos, int32_t* out_leaf_lcp, int32_t* out_seq_leaf, int32_t* out_M,
                 void* stream);
 
@@ -93,6 +95,14 @@ int dta_tree_attn_fwd(const void* q, const void* k, const void* v, void* out, fl
                       int64_t q_stride_t, int64_t kv_stride_t, int64_t o_stride_t,
                       float scale, int32_t dtype, void* stream);
 
+/* General-stride form of dta_tree_attn_fwd: explicit head strides (elements) so that head-major
+ * layouts such as the reference's [1, H, S, D] KV stack (tree_training_engine.py:108-131) work in place. */
+int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse,
+                         const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
+                         int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                         int64_t q_stride_t, int64_t q_stride_h, int64_t kv_stride_t, int64_t kv_stride_h,
+                         int64_t o_stride_t, int64_t o_stride_h, float scale, int32_t dtype, void* stream);
+
 /* Backward.  Two launches on `stream`: (1) per query tile: delta = rowsum(dout*out), dq;
  * (2) per key tile of DTA_KTILE keys: dk, dv summed over the query range
  * [max(key0, q_offset), ktile_qend[tile]) and over the Hq/Hkv query heads of the group — no
@@ -108,6 +118,17 @@ int dta_tree_attn_bwd(const void* q, const void* k, const void* v, const void* o
                       int64_t q_stride_t, int64_t kv_stride_t, int64_t o_stride_t,
                       int64_t dq_stride_t, int64_t dkv_stride_t,
                       float scale, int32_t dtype, int32_t accumulate, void* stream);
+
+int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                         const float* lse, float* delta, void* dq, void* dk, void* dv,
+                         const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
+                         const int32_t* ktile_qend,
+                         int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                         int64_t q_stride_t, int64_t q_stride_h, int64_t kv_stride_t, int64_t kv_stride_h,
+                         int64_t o_stride_t, int64_t o_stride_h, int64_t dq_stride_t, int64_t dq_stride_h,
+                         int64_t dkv_stride_t, int64_t dkv_stride_h,
+                         float scale, int32_t dtype, int32_t accumulate,
+                         int32_t which /* bit0: delta+dq launch, bit1: dk/dv launch (needs delta) */, void* stream);
 
 #ifdef __cplusplus
 }

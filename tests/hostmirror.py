@@ -1,0 +1,63 @@
+"""CPU stand-ins for the product's three device steps, for `-m "not gpu"` tests of the HOST logic
+only (sorting, leaf grouping, permutation, packing plan, loss assembly, balancers).  They are
+installed by monkeypatching from tests; the product never imports this module or the oracle."""
+import numpy as np
+import torch
+
+from oracle import attn_oracle, trie_oracle
+
+
+def expand_plan_host(plan):
+    """numpy mirror of dta_preorder_meta's index arithmetic -> (depth, parent, subtree_end)."""
+    T, M = plan.T, plan.M
+    seg = np.repeat(np.arange(M, dtype=np.int32), np.diff(plan.seg_off))
+    j = np.arange(T, dtype=np.int32) - plan.seg_off[seg]
+    depth = (plan.seg_depth0[seg] + j).astype(np.int32)
+    parent = np.where(j > 0, np.arange(T, dtype=np.int32) - 1, plan.parent_of_seg[seg]).astype(np.int32)
+    se = np.empty(T, np.int32)
+    for i in range(M):
+        a, b = plan.brk_ptr[i], plan.brk_ptr[i + 1]
+        s, e = plan.seg_off[i], plan.seg_off[i + 1]
+        if e > s:
+            k = np.searchsorted(plan.brk_depth[a:b], depth[s:e], side="right") - 1
+            se[s:e] = plan.brk_end[a:b][k]
+    return seg, depth, parent, se
+
+
+def _cpu_trie_arrays(dev, order, leafize):
+    toks = dev.tokens.numpy()
+    seqs = [toks[dev.starts[i]:dev.starts[i] + dev.lens[i]] for i in order]
+    lcp, unsorted = [], 0
+    for a, b in zip(seqs[:-1], seqs[1:]):
+        c = trie_oracle.lcp_pair(a, b)
+        unsorted += int(c < min(len(a), len(b)) and a[c] > b[c])
+        lcp.append(c)
+    if not leafize:
+        return lcp, unsorted, None
+    S = len(seqs)
+    keep = [i for i in range(S) if i == S - 1 or lcp[i] < min(len(seqs[i]), len(seqs[i + 1]))]
+    return [lcp[i] for i in keep[:-1]], unsorted, keep
+
+
+def _cpu_expand(self, tokens, leaf_off, seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, M, T):
+    seg, depth, parent, se = expand_plan_host(self.plan)
+    self.depth.copy_(torch.from_numpy(depth)); self.parent.copy_(torch.from_numpy(parent)); self.subtree_end.copy_(torch.from_numpy(se))
+    src = leaf_off.numpy()[seg] + depth
+    self.tokens.copy_(tokens[torch.from_numpy(src)])
+
+
+def _cpu_attention(q, k, v, meta, scale=None):
+    T = q.shape[0]
+    if meta.subtree_end is None:
+        se = torch.full((k.shape[0],), meta.q_offset + T, dtype=torch.long)
+        assert meta.q_offset == 0
+    else:
+        se = meta.subtree_end.long()
+    return attn_oracle.tree_attention(q, k, v, se, scale)[0]
+
+
+def install(monkeypatch):
+    from dynamictreeattn_amd import ops, token_trie, tree_training_engine
+    monkeypatch.setattr(token_trie, "_device_trie_arrays", _cpu_trie_arrays)
+    monkeypatch.setattr(tree_training_engine._PackedTrie, "_expand", _cpu_expand)
+    monkeypatch.setattr(ops, "tree_attention", _cpu_attention)

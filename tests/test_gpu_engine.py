@@ -1,0 +1,94 @@
+"""GPU parity of the whole hot path (TokenTrie HIP kernels -> packed engine -> HIP tree attention ->
+loss -> backward) in bf16 against (a) the reference's fp32 results in tests/golden/engine_tiny.pt,
+(b) the product's own dense path, with the reference's recorded bf16 bound as the bar."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dynamictreeattn_amd import dense, synth
+from dynamictreeattn_amd.model import Qwen3TreeLM
+from dynamictreeattn_amd.token_trie import TokenTrie
+from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine
+from oracle import model_oracle as mo
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = torch.device("cuda:0")
+REF_BF16_BOUND = 1.0636e-01          # grad/Qwen3-0.6B-TB-vs-DB-bf16.txt:6 (max |Δg|/|g| over 310 params)
+
+
+@pytest.fixture(scope="module")
+def eng_gold():
+    return torch.load(os.path.join(GOLD, "engine_tiny.pt"), weights_only=True)
+
+
+def _att(n):
+    return [{"w_logprobs": -1.0 - 0.01 * i, "w_entropy": 0.1 + 0.003 * i} for i in range(n)]
+
+
+def _setup(name, dtype):
+    case = synth.engine_cases()[name]
+    cfg = synth.TINY_CFGS[case["cfg"]]
+    w = mo.init_weights(cfg, seed=case["wseed"])
+    return Qwen3TreeLM.from_named(cfg, w, DEV, dtype), synth.as_tensors(synth.make_case(case["data"]))
+
+
+@pytest.mark.parametrize("name", ["d128_minitau", "d128_tree"])
+def test_forward_logprobs_bf16_vs_reference_fp32(name, eng_gold):
+    m, seqs = _setup(name, torch.bfloat16); g = eng_gold[name]
+    for perm in ("idx", "forward"):
+        t = TokenTrie(seqs)
+        if perm == "forward":
+            t.forward_permute()
+        out = TreeTrainingEngine(m.config, DEV, torch.bfloat16, max(map(len, seqs)), forward_only=True).forward(m, t)
+        for a, b in zip(out, g[f"fwd_{perm}"]):
+            assert a.dtype == torch.float32 and a.shape == b.shape
+            assert (a.cpu() - b).abs().max() < 0.08 and (a.cpu() - b).abs().mean() < 0.015      # bf16 model vs fp32 reference
+
+
+@pytest.mark.parametrize("name", ["d128_minitau", "d128_tree"])
+@pytest.mark.parametrize("perm", ["ours", "idx"])
+def test_backward_bf16_vs_reference_fp32(name, perm, eng_gold):
+    m, seqs = _setup(name, torch.bfloat16); g = eng_gold[name]
+    t = TokenTrie(seqs, _att(len(seqs)))
+    if perm == "ours":
+        t.backward_permute()
+    loss = TreeTrainingEngine(m.config, DEV, torch.bfloat16, max(map(len, seqs))).backward(m, t, mo.default_loss, 2048)
+    assert abs(loss - g["bwd_bs2048_loss"]) < 1e-2 * abs(loss)
+    ratios = {n: mo.grad_ratio(g["bwd_bs2048_grads"][n], p.grad.float().cpu()) for n, p in m.named_parameters()}
+    assert max(ratios.values()) <= REF_BF16_BOUND, max(ratios.items(), key=lambda kv: kv[1])
+    assert float(np.median(list(ratios.values()))) <= 2.55e-2
+
+
+@pytest.mark.parametrize("name", ["d128_minitau", "d128_tree"])
+def test_tree_equals_dense_on_gpu(name):
+    """exp/compare_grads.py protocol: tree backward vs dense backward, same model, same kernels."""
+    m, seqs = _setup(name, torch.bfloat16)
+    t = TokenTrie(seqs, _att(len(seqs))); t.backward_permute()
+    lt = TreeTrainingEngine(m.config, DEV, torch.bfloat16, max(map(len, seqs))).backward(m, t, mo.default_loss, 2048)
+    gt = {n: p.grad.float().clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    ld = dense.backward(m, seqs, _att(len(seqs)), mo.default_loss)
+    assert abs(lt - ld) < 5e-3 * abs(ld)
+    ratios = [mo.grad_ratio(p.grad.float(), gt[n]) for n, p in m.named_parameters()]
+    assert max(ratios) <= REF_BF16_BOUND and float(np.median(ratios)) <= 2.55e-2
+    lps = dense.forward(m, seqs)
+    t2 = TokenTrie(seqs); t2.forward_permute()
+    out = TreeTrainingEngine(m.config, DEV, torch.bfloat16, max(map(len, seqs)), forward_only=True).forward(m, t2)
+    for a, b in zip(out, lps):
+        assert (a - b).abs().max() < 0.06
+
+
+def test_f16_and_layer_checkpointing_agree():
+    m, seqs = _setup("d128_tree", torch.float16)
+    t = TokenTrie(seqs, _att(len(seqs))); t.backward_permute()
+    e = TreeTrainingEngine(m.config, DEV, torch.float16, 4096)
+    l1 = e.backward(m, t, mo.default_loss, 2048)
+    g1 = {n: p.grad.float().clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    e.checkpoint_layers = True
+    l2 = e.backward(m, t, mo.default_loss, 64)
+    assert abs(l1 - l2) < 1e-3 * abs(l1)
+    assert max(mo.grad_ratio(g1[n], p.grad.float()) for n, p in m.named_parameters()) < 5e-3

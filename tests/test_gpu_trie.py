@@ -1,0 +1,89 @@
+"""GPU parity (bit-exact): dta_lcp_adjacent / dta_leafize / dta_preorder_meta through the product's
+TokenTrie and packed engine metadata, against the reference-generated fixtures, the oracle, and —
+at BASELINE sizes — the C oracle and size-independent properties."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hostmirror
+from dynamictreeattn_amd import packing, synth
+from dynamictreeattn_amd.token_trie import TokenTrie, _DeviceTokens, _device_trie_arrays
+from oracle import trie_oracle as to
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _attach_table(t):
+    return [[[a["_sequence_batch_id"], n] for a, n in al] for al in t.attach_lists]
+
+
+def test_tokentrie_all_fixture_cases_bit_exact(trie_golden):
+    for item in trie_golden["cases"]:
+        seqs = synth.as_tensors(synth.make_case(item["case"])); ref = item["ref"]
+        t = TokenTrie(seqs)
+        assert t.lens == ref["lens"] and t.lcp_lens == ref["lcp_lens"] and _attach_table(t) == ref["attach"], item["case"]
+        for name in ("forward_permute", "backward_permute"):
+            t2 = TokenTrie(synth.as_tensors(synth.make_case(item["case"]))); getattr(t2, name)()
+            assert t2.lens == ref[name]["lens"] and t2.lcp_lens == ref[name]["lcp_lens"] and _attach_table(t2) == ref[name]["attach"]
+
+
+def test_unsorted_flag_raises_like_reference():
+    with pytest.raises(ValueError, match="Input_ids not sorted in lexicographic order."):
+        TokenTrie(synth.as_tensors([[5, 1], [3, 2]]), sorted=True)
+    TokenTrie(synth.as_tensors([[3, 2], [5, 1]]), sorted=True)
+
+
+def test_edge_cases():
+    t = TokenTrie(synth.as_tensors([[7]]))
+    assert (t.lens, t.lcp_lens, t.n_tokens) == ([1], [], 1)
+    seqs = [[1] * 5000, [1] * 4999 + [2], [1] * 1023 + [3], [1] * 1024 + [4], [1] * 1025 + [0]]
+    t = TokenTrie(synth.as_tensors(seqs))
+    o = to.TokenTrieOracle([np.array(s) for s in seqs])
+    assert t.lens == o.lens and t.lcp_lens == o.lcp_lens        # mismatches exactly at 1024-step boundaries
+
+
+def test_full_size_lcp_vs_c_oracle():
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liblcp_oracle.so"))
+    dev = torch.device("cuda:0")
+    for case in ({"kind": "wide", "seed": 1}, {"kind": "tau2", "seed": 5, "G": 16, "turns": 12, "lo": 400, "hi": 1800}):
+        seqs = synth.as_tensors(synth.make_case(case))
+        keys = [s.numpy().astype(">u8").tobytes() for s in seqs]
+        order = sorted(range(len(seqs)), key=keys.__getitem__)
+        d = _DeviceTokens(seqs, dev)
+        lcp, unsorted, leaf_pos = _device_trie_arrays(d, order, True)
+        S = len(seqs)
+        toks = np.concatenate([s.numpy() for s in seqs]); starts = d.starts[order].astype(np.int64); lens = d.lens[order].astype(np.int32)
+        out = np.zeros(S, np.int32); bad = np.zeros(1, np.int32)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        lib.lcp_adjacent(P(toks), P(starts), P(lens), S, P(out), P(bad))
+        lp = np.zeros(S, np.int32); ll = np.zeros(S, np.int32); sl = np.zeros(S, np.int32)
+        M = lib.leafize_keep(P(lens), P(out), S, P(lp), P(ll), P(sl))
+        assert unsorted == 0 and bad[0] == 0
+        assert leaf_pos == lp[:M].tolist() and lcp == ll[:M - 1].tolist()
+        # property: sorted order => lcp[i] tokens really agree and the next one does not
+        for i in range(0, S - 1, max(1, S // 16)):
+            a, b = seqs[order[i]], seqs[order[i + 1]]
+            c = int(out[i]); assert torch.equal(a[:c], b[:c]) and (c == min(len(a), len(b)) or a[c] < b[c])
+
+
+def test_preorder_meta_kernel_vs_host_mirror():
+    from dynamictreeattn_amd.tree_training_engine import _PackedTrie
+    dev = torch.device("cuda:0")
+    for case in synth.trie_cases()[:14] + synth.trie_cases()[20:30]:
+        seqs = synth.as_tensors(synth.make_case(case))
+        for perm in ("forward_permute", "backward_permute"):
+            t = TokenTrie(seqs); getattr(t, perm)()
+            pk = _PackedTrie(t, dev)
+            seg, depth, parent, se = hostmirror.expand_plan_host(pk.plan)
+            assert pk.depth.cpu().numpy().tolist() == depth.tolist()
+            assert pk.parent.cpu().numpy().tolist() == parent.tolist()
+            assert pk.subtree_end.cpu().numpy().tolist() == se.tolist()
+            # packed tokens: every leaf's root path spells the leaf
+            tok = pk.tokens.cpu()
+            for i, leaf in enumerate(t.inputs):
+                assert torch.equal(tok[pk.paths[i].cpu()], leaf)
+            assert int(pk.meta.ktile_qend.max()) == pk.plan.T
