@@ -68,26 +68,57 @@ def allreduce_grads(model, bucket_elems: int = 1 << 28):
             g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
 
 
-def cpu_baseline(threads: int):
+def host_threads() -> int:
+    """Cores this process may actually use (the GPU box gives one GPU's share, 16), not os.cpu_count()."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def cpu_baseline_worker():
     """The oracle's restatement of the reference push/pop schedule (tree_training_engine.py:555-616) on
-    the host cores, Qwen3-0.6B dims bf16, on a bounded tau2-shaped sample."""
+    the host cores, Qwen3-0.6B dims, on a bounded tau2-shaped sample.  Runs in a child process."""
     import numpy as np
     from oracle import model_oracle as mo
     from oracle import trie_oracle as to
+    threads = host_threads()
     torch.set_num_threads(threads)
+    flags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
+    dtype = torch.bfloat16 if ("avx512_bf16" in flags or "amx_bf16" in flags) else torch.float32    # reference dtypes: run.py:122-126
     case = {"kind": "tau2", "seed": 0, "G": 2, "sys_len": 500, "turns": 3, "lo": 50, "hi": 225, "cap": 4096}
     seqs = [np.asarray(s, dtype=np.int64) for s in synth.make_case(case)]
-    w = {k: v.requires_grad_(True) for k, v in mo.init_weights(mo.QWEN3_0P6B, seed=0, dtype=torch.bfloat16).items()}
+    w = {k: v.requires_grad_(True) for k, v in mo.init_weights(mo.QWEN3_0P6B, seed=0, dtype=dtype).items()}
     t0 = time.time()
     trie = to.TokenTrieOracle(seqs, [dict(ATTACH) for _ in seqs]); trie.backward_permute()
-    eng = mo.StackEngineOracle(mo.QWEN3_0P6B, w, max(len(s) for s in seqs), dtype=torch.bfloat16)
+    eng = mo.StackEngineOracle(mo.QWEN3_0P6B, w, max(len(s) for s in seqs), dtype=dtype)
     eng.backward(trie, mo.default_loss, 2048)
     dt = time.time() - t0
     st = trie.get_stats("backward", 2048)
-    return {"value": st["n_tokens"] / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-            "sample": f"tau2-shaped call at 1/4 length scale (G=2, sys 500, 3 turns of 50-225): {st['n_sequences']} seqs, "
-                      f"{st['n_tokens']} tokens, {st['n_tree_tokens']} tree tokens, bf16, block_size 2048, {dt:.1f} s",
-            "tree_tokens_per_s": st["n_tree_tokens"] / dt}
+    name = "bf16" if dtype == torch.bfloat16 else "fp32 (host has no avx512_bf16/amx)"
+    print("CPU_BASELINE " + json.dumps({
+        "value": st["n_tokens"] / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
+        "sample": f"tau2-shaped call at 1/4 length scale (G=2, sys 500, 3 turns of 50-225): {st['n_sequences']} seqs, "
+                  f"{st['n_tokens']} tokens, {st['n_tree_tokens']} tree tokens, Qwen3-0.6B {name}, reference push/pop schedule, "
+                  f"block_size 2048, {dt:.1f} s",
+        "tree_tokens_per_s": st["n_tree_tokens"] / dt}), flush=True)
+
+
+def cpu_baseline(limit_s: int = 240):
+    """Bounded: the child is killed after `limit_s` and the leg reports null instead of stalling the bench."""
+    import subprocess
+    print(f"[bench] timing the CPU baseline (oracle, host cores) in a child process, limit {limit_s}s ...", file=sys.stderr, flush=True)
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True, text=True,
+                           timeout=limit_s, env=env)
+        for line in r.stdout.splitlines():
+            if line.startswith("CPU_BASELINE "):
+                return json.loads(line[len("CPU_BASELINE "):])
+        return {"value": None, "unit": "tokens/s", "cores": host_threads(), "kind": "port", "sample": "worker failed: " + r.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "tokens/s", "cores": host_threads(), "kind": "port", "sample": f"worker exceeded {limit_s}s and was stopped"}
 
 
 def main():
@@ -97,8 +128,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--block-size", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--model", default="qwen3-0.6b", choices=["qwen3-0.6b", "qwen3-4b"])
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -202,7 +236,7 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

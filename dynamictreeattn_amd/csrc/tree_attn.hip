@@ -523,6 +523,7 @@ extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v,
   const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
   dim3 grid(nqt * Hq), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  (void)hipGetLastError();   // drop a stale error of an earlier, unrelated runtime call
   if (dtype == DTA_BF16) hipLaunchKernelGGL(tree_attn_fwd_kernel<DTA_BF16>, grid, block, 0, st, p);
   else hipLaunchKernelGGL(tree_attn_fwd_kernel<DTA_F16>, grid, block, 0, st, p);
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
@@ -550,6 +551,7 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
   const int nkt = (Tk + DTA_KTILE - 1) / DTA_KTILE;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  (void)hipGetLastError();   // drop a stale error of an earlier, unrelated runtime call
   if ((which & 3) == 0) return DTA_EINVAL;
   if (dtype == DTA_BF16) {
     if (which & 1) hipLaunchKernelGGL(tree_attn_bwd_dq_kernel<DTA_BF16>, dim3(nqt * Hq), dim3(256), 0, st, p);

@@ -112,6 +112,7 @@ extern "C" int dta_lcp_adjacent(const int64_t* tokens, const int64_t* starts, co
                                 int32_t* out_lcp, int32_t* out_unsorted, void* stream) {
   if (!tokens || !starts || !lens || !out_unsorted || S < 1 || (S > 1 && !out_lcp)) return DTA_EINVAL;
   if (S == 1) return DTA_OK;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(lcp_adjacent_kernel, dim3(S - 1), dim3(256), 0, static_cast<hipStream_t>(stream), tokens, starts, lens, S, out_lcp, out_unsorted);
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
 }
@@ -120,6 +121,7 @@ extern "C" int dta_leafize(const int32_t* lens, const int32_t* lcp, int32_t S,
                            int32_t* out_leaf_pos, int32_t* out_leaf_lcp, int32_t* out_seq_leaf, int32_t* out_M, void* stream) {
   if (!lens || !out_leaf_pos || !out_leaf_lcp || !out_seq_leaf || !out_M || S < 1 || (S > 1 && !lcp)) return DTA_EINVAL;
   if (S > (1 << 20)) return DTA_EUNSUPPORTED;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(leafize_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), lens, lcp, S, out_leaf_pos, out_leaf_lcp, out_seq_leaf, out_M);
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
 }
@@ -132,6 +134,7 @@ extern "C" int dta_preorder_meta(const int64_t* tokens, const int64_t* leaf_tok_
   if (!tokens || !leaf_tok_off || !seg_off || !seg_depth0 || !parent_of_seg || !brk_ptr || !brk_depth || !brk_end ||
       !out_token || !out_depth || !out_parent || !out_subtree_end || M < 1 || T < 1) return DTA_EINVAL;
   int blocks = (T + 255) / 256; if (blocks > 2048) blocks = 2048;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(preorder_meta_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), tokens, leaf_tok_off, seg_off, seg_depth0,
                      parent_of_seg, brk_ptr, brk_depth, brk_end, M, T, out_token, out_depth, out_parent, out_subtree_end);
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
