@@ -185,3 +185,26 @@ def test_engine_backward_fp32_vs_reference(name, perm, eng_gold):
         assert mo.grad_ratio(g["bwd_bs2048_grads"][n], p.grad) <= 2e-5, (name, n)
     with pytest.raises(AssertionError, match="Exceeds max_seq_len"):
         TreeTrainingEngine(m.config, CPU, torch.float32, 3).backward(m, t, mo.default_loss, 2048)
+
+
+def test_engine_accepts_a_huggingface_module_by_duck_typing(eng_gold):
+    """the engine drives an HF Qwen3ForCausalLM through its own nn.Parameters."""
+    transformers = pytest.importorskip("transformers")
+    name = "d128_minitau"
+    case = synth.engine_cases()[name]; cfg = synth.TINY_CFGS[case["cfg"]]
+    c = transformers.Qwen3Config(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+                                 num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+                                 num_key_value_heads=cfg["num_key_value_heads"], head_dim=cfg["head_dim"], tie_word_embeddings=True,
+                                 rms_norm_eps=cfg["rms_norm_eps"], rope_parameters={"rope_type": "default", "rope_theta": cfg["rope_theta"]})
+    hf = transformers.Qwen3ForCausalLM(c)
+    w = mo.init_weights(cfg, seed=case["wseed"])
+    hf.load_state_dict({**w, "lm_head.weight": w["model.embed_tokens.weight"]}, strict=False)
+    hf = hf.float().train()
+    seqs = synth.as_tensors(synth.make_case(case["data"]))
+    t = TokenTrie(seqs, _att(len(seqs)), device=CPU); t.backward_permute()
+    loss = TreeTrainingEngine(hf.config, CPU, torch.float32, 64).backward(hf, t, mo.default_loss, 2048)
+    g = eng_gold[name]
+    assert abs(loss - g["bwd_bs2048_loss"]) < 2e-4 * abs(loss)
+    for n, p in hf.named_parameters():
+        if n in g["bwd_bs2048_grads"]:
+            assert mo.grad_ratio(g["bwd_bs2048_grads"][n], p.grad) <= 2e-5, n
