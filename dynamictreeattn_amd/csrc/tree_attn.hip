@@ -29,6 +29,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector (HIP's uint4 class kept staging arrays in scratch)
 
 template <int DT> struct Ty;
 template <> struct Ty<DTA_BF16> {
@@ -116,21 +117,50 @@ struct TileIter {
   }
 };
 
+// -------------------------------------------------------------------------------------------------
+// Staging macros (no lambdas: captured arrays were demoted to scratch by hipcc).
+// A 64-row x 128-col tile pair (A image + B image, 32 KB) is moved by NT threads; every thread owns
+// CPT 16-byte chunks of each image: chunk id = tid + NT*i -> row = id >> 4, chunk-in-row = id & 15.
+// -------------------------------------------------------------------------------------------------
+#define DTA_STAGE_LOAD(REGA, REGB, BASEA, BASEB, STRIDE_A, STRIDE_B, ROW0, ROWMAX, NT, CPT)                \
+  _Pragma("unroll") for (int i_ = 0; i_ < (CPT); ++i_) {                                                  \
+    const int id_ = tid + (NT) * i_, row_ = id_ >> 4, ch_ = id_ & 15;                                      \
+    int gr_ = (ROW0) + row_; gr_ = gr_ < (ROWMAX) ? gr_ : (ROWMAX) - 1;                                    \
+    REGA[i_] = *reinterpret_cast<const u32x4*>((BASEA) + (int64_t)gr_ * (STRIDE_A) + ch_ * 8);             \
+    REGB[i_] = *reinterpret_cast<const u32x4*>((BASEB) + (int64_t)gr_ * (STRIDE_B) + ch_ * 8);             \
+  }
+#define DTA_STAGE_WRITE(REGA, REGB, IMGA, IMGB, NT, CPT)                                                  \
+  _Pragma("unroll") for (int i_ = 0; i_ < (CPT); ++i_) {                                                  \
+    const int id_ = tid + (NT) * i_, row_ = id_ >> 4, ch_ = id_ & 15;                                      \
+    *reinterpret_cast<u32x4*>((IMGA) + img_off(row_, ch_)) = REGA[i_];                                     \
+    *reinterpret_cast<u32x4*>((IMGB) + img_off(row_, ch_)) = REGB[i_];                                     \
+  }
+
+constexpr int SE_BYTES = 256;                                       // 64 x int32 subtree_end of the staged keys
+constexpr int QK_LDS = 2 * (2 * TILE_BYTES + SE_BYTES);            // double-buffered {K image, V image, se}
+
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
 // =================================================================================================
-// forward
+// forward.  HPB = query heads of one kv group handled by a workgroup (waves 4*hb .. 4*hb+3 own head hb);
+// they share the staged K/V tiles.  One barrier per 64-key tile, LDS double buffered.
 // =================================================================================================
-template <int DT>
-__global__ __launch_bounds__(256) void tree_attn_fwd_kernel(AttnParams p) {
+template <int DT, int HPB>
+__global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams p) {
   using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 256];
-  char* Ks = smem; char* Vs = smem + TILE_BYTES; int* se_s = reinterpret_cast<int*>(smem + 2 * TILE_BYTES);
+  constexpr int NT = 256 * HPB, CPT = 1024 / NT;
+  __shared__ __attribute__((aligned(16))) char smem[QK_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int hb = wave >> 2, rw = wave & 3;
   const int bid = blockIdx.x;
-  const int kvh = bid % p.Hkv; const int rest = bid / p.Hkv; const int hg = rest % p.group; const int qt = rest / p.group;
-  const int hq = kvh * p.group + hg;
+  const int hgroups = p.group / HPB;
+  const int kvh = bid % p.Hkv; const int rest = bid / p.Hkv; const int hgb = rest % hgroups;
+  const int nqt = (p.Tq + DTA_QTILE - 1) / DTA_QTILE;
+  const int qt = nqt - 1 - rest / hgroups;                          // deepest (heaviest) query tiles first
+  const int hq = kvh * p.group + hgb * HPB + hb;
   const int q0 = qt * DTA_QTILE;
-  const int qrow = q0 + wave * 32 + r;
+  const int qrow = q0 + rw * 32 + r;
   const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
   const int qidx = p.q_offset + qrow;
 
@@ -145,27 +175,14 @@ __global__ __launch_bounds__(256) void tree_attn_fwd_kernel(AttnParams p) {
 
   const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
   const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.kv_sh;
-
-  uint4 kreg[4], vreg[4]; int sereg = 0;
-  auto stage_load = [&](int k0, int kend) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
-      int kr = k0 + row; kr = kr < p.Tk ? kr : p.Tk - 1;
-      kreg[i] = *reinterpret_cast<const uint4*>(kbase + (int64_t)kr * p.kv_st + ch * 8);
-      vreg[i] = *reinterpret_cast<const uint4*>(vbase + (int64_t)kr * p.kv_st + ch * 8);
-    }
-    if (tid < 64) { const int ki = k0 + tid; sereg = (ki < kend) ? (p.subtree_end ? p.subtree_end[ki] : 0x7fffffff) : 0; }
-  };
-  auto stage_write = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
-      *reinterpret_cast<uint4*>(Ks + img_off(row, ch)) = kreg[i];
-      *reinterpret_cast<uint4*>(Vs + img_off(row, ch)) = vreg[i];
-    }
-    if (tid < 64) se_s[tid] = sereg;
-  };
+  u32x4 kreg[CPT], vreg[CPT]; int sereg = 0;
+#define FWD_LOAD(K0, KEND)                                                                                 \
+  { DTA_STAGE_LOAD(kreg, vreg, kbase, vbase, p.kv_st, p.kv_st, (K0), p.Tk, NT, CPT)                        \
+    if (tid < 64) { const int ki_ = (K0) + tid; sereg = (ki_ < (KEND)) ? (p.subtree_end ? p.subtree_end[ki_] : 0x7fffffff) : 0; } }
+#define FWD_WRITE(B)                                                                                       \
+  { char* base_ = smem + (B) * (2 * TILE_BYTES + SE_BYTES);                                                \
+    DTA_STAGE_WRITE(kreg, vreg, base_, base_ + TILE_BYTES, NT, CPT)                                        \
+    if (tid < 64) reinterpret_cast<int*>(base_ + 2 * TILE_BYTES)[tid] = sereg; }
 
   f32x16 O[4];
 #pragma unroll
@@ -175,12 +192,22 @@ __global__ __launch_bounds__(256) void tree_attn_fwd_kernel(AttnParams p) {
   float m = -1e30f, lsum = 0.f;
   const float c = p.scale * LOG2E;
 
-  stage_load(it.k0, it.kend); stage_write(); __syncthreads();
   int ck0 = it.k0; bool cmask = it.masked();
+  FWD_LOAD(it.k0, it.kend) FWD_WRITE(0)
+  bool has_next = it.advance();
+  int nk0 = it.k0; bool nmask = has_next ? it.masked() : false;
+  if (has_next) FWD_LOAD(it.k0, it.kend)
+  __syncthreads();
+  int cur = 0;
   while (true) {
-    const bool has_next = it.advance();
-    if (has_next) stage_load(it.k0, it.kend);
-
+    bool has_next2 = false;
+    if (has_next) {
+      FWD_WRITE(cur ^ 1)
+      has_next2 = it.advance();
+      if (has_next2) FWD_LOAD(it.k0, it.kend)
+    }
+    const char* Ks = smem + cur * (2 * TILE_BYTES + SE_BYTES); const char* Vs = Ks + TILE_BYTES;
+    const int* se_s = reinterpret_cast<const int*>(Ks + 2 * TILE_BYTES);
     // ---- S^T[key][q] = K · Q^T -----------------------------------------------------------------
     f32x16 X[2];
 #pragma unroll
@@ -190,36 +217,43 @@ __global__ __launch_bounds__(256) void tree_attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) X[kb] = T::mma(row_frag<v8>(Ks, 32 * kb + r, 2 * s + h), qf[s], X[kb]);
     }
-    // ---- mask + online softmax (log2 domain) ---------------------------------------------------
-    float mx = -INFINITY;
     if (cmask) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int kl = 32 * kb + 8 * (g >> 2) + 4 * h + (g & 3);
-          const bool ok = (ck0 + kl <= qidx) && (qidx < se_s[kl]);
-          const float t = ok ? X[kb][g] * c : -INFINITY;
-          X[kb][g] = t; mx = fmaxf(mx, t);
+        for (int gq = 0; gq < 4; ++gq) {
+          const int kl = 32 * kb + 8 * gq + 4 * h;
+          const int4 se4 = *reinterpret_cast<const int4*>(se_s + kl);
+          const int sev[4] = {se4.x, se4.y, se4.z, se4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool ok = (ck0 + kl + j <= qidx) && (qidx < sev[j]);
+            X[kb][4 * gq + j] = ok ? X[kb][4 * gq + j] : -INFINITY;
+          }
         }
-    } else {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) { const float t = X[kb][g] * c; X[kb][g] = t; mx = fmaxf(mx, t); }
     }
+    // ---- online softmax, log2 domain; O is rescaled only when some row's maximum really grew -------
+    float mx = max3(X[0][0], X[0][1], X[0][2]);
+#pragma unroll
+    for (int g = 3; g < 15; g += 2) mx = max3(mx, X[0][g], X[0][g + 1]);
+    mx = fmaxf(mx, X[0][15]);
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) mx = max3(mx, X[1][g], X[1][g + 1]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mnew = fmaxf(m, mx);
-    const float alpha = fast_exp2(m - mnew);
-    m = mnew; lsum *= alpha;
+    const float mc = mx * c;
+    if (__any(mc > m)) {
+      const float mnew = fmaxf(m, mc);
+      const float alpha = fast_exp2(m - mnew);
+      m = mnew; lsum *= alpha;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+      for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) O[db][g] *= alpha;
+        for (int g = 0; g < 16; ++g) O[db][g] *= alpha;
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) { const float pv = fast_exp2(X[kb][g] - mnew); lsum += pv; X[kb][g] = pv; }
+      for (int g = 0; g < 16; ++g) { const float pv = fast_exp2(__builtin_fmaf(X[kb][g], c, -m)); lsum += pv; X[kb][g] = pv; }
     // ---- O^T[d][q] += V^T · P^T ------------------------------------------------------------------
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
@@ -229,9 +263,11 @@ __global__ __launch_bounds__(256) void tree_attn_fwd_kernel(AttnParams p) {
     }
     __syncthreads();
     if (!has_next) break;
-    stage_write(); __syncthreads();
-    ck0 = it.k0; cmask = it.masked();
+    cur ^= 1; ck0 = nk0; cmask = nmask;
+    has_next = has_next2; nk0 = it.k0; nmask = has_next2 ? it.masked() : false;
   }
+#undef FWD_LOAD
+#undef FWD_WRITE
 
   lsum += __shfl_xor(lsum, 32);
   const float inv = 1.f / lsum;
@@ -253,18 +289,22 @@ __global__ __launch_bounds__(256) void tree_attn_fwd_kernel(AttnParams p) {
 // =================================================================================================
 // backward part 1: delta + dQ   (query tile owns the workgroup; same sweep as the forward)
 // =================================================================================================
-template <int DT>
-__global__ __launch_bounds__(256) void tree_attn_bwd_dq_kernel(AttnParams p) {
+template <int DT, int HPB>
+__global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_kernel(AttnParams p) {
   using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 256];
-  char* Ks = smem; char* Vs = smem + TILE_BYTES; int* se_s = reinterpret_cast<int*>(smem + 2 * TILE_BYTES);
+  constexpr int NT = 256 * HPB, CPT = 1024 / NT;
+  __shared__ __attribute__((aligned(16))) char smem[QK_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int hb = wave >> 2, rw = wave & 3;
   const int bid = blockIdx.x;
-  const int kvh = bid % p.Hkv; const int rest = bid / p.Hkv; const int hg = rest % p.group; const int qt = rest / p.group;
-  const int hq = kvh * p.group + hg;
+  const int hgroups = p.group / HPB;
+  const int kvh = bid % p.Hkv; const int rest = bid / p.Hkv; const int hgb = rest % hgroups;
+  const int nqt = (p.Tq + DTA_QTILE - 1) / DTA_QTILE;
+  const int qt = nqt - 1 - rest / hgroups;
+  const int hq = kvh * p.group + hgb * HPB + hb;
   const int q0 = qt * DTA_QTILE;
-  const int qrow = q0 + wave * 32 + r;
+  const int qrow = q0 + rw * 32 + r;
   const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
   const int qidx = p.q_offset + qrow;
 
@@ -293,26 +333,14 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dq_kernel(AttnParams p) {
 
   const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
   const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.kv_sh;
-  uint4 kreg[4], vreg[4]; int sereg = 0;
-  auto stage_load = [&](int k0, int kend) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
-      int kr = k0 + row; kr = kr < p.Tk ? kr : p.Tk - 1;
-      kreg[i] = *reinterpret_cast<const uint4*>(kbase + (int64_t)kr * p.kv_st + ch * 8);
-      vreg[i] = *reinterpret_cast<const uint4*>(vbase + (int64_t)kr * p.kv_st + ch * 8);
-    }
-    if (tid < 64) { const int ki = k0 + tid; sereg = (ki < kend) ? (p.subtree_end ? p.subtree_end[ki] : 0x7fffffff) : 0; }
-  };
-  auto stage_write = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
-      *reinterpret_cast<uint4*>(Ks + img_off(row, ch)) = kreg[i];
-      *reinterpret_cast<uint4*>(Vs + img_off(row, ch)) = vreg[i];
-    }
-    if (tid < 64) se_s[tid] = sereg;
-  };
+  u32x4 kreg[CPT], vreg[CPT]; int sereg = 0;
+#define DQ_LOAD(K0, KEND)                                                                                  \
+  { DTA_STAGE_LOAD(kreg, vreg, kbase, vbase, p.kv_st, p.kv_st, (K0), p.Tk, NT, CPT)                        \
+    if (tid < 64) { const int ki_ = (K0) + tid; sereg = (ki_ < (KEND)) ? (p.subtree_end ? p.subtree_end[ki_] : 0x7fffffff) : 0; } }
+#define DQ_WRITE(B)                                                                                        \
+  { char* base_ = smem + (B) * (2 * TILE_BYTES + SE_BYTES);                                                \
+    DTA_STAGE_WRITE(kreg, vreg, base_, base_ + TILE_BYTES, NT, CPT)                                        \
+    if (tid < 64) reinterpret_cast<int*>(base_ + 2 * TILE_BYTES)[tid] = sereg; }
 
   f32x16 DQ[4];
 #pragma unroll
@@ -322,45 +350,63 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dq_kernel(AttnParams p) {
   const float c = p.scale * LOG2E;
 
   if (any) {
-    stage_load(it.k0, it.kend); stage_write(); __syncthreads();
     int ck0 = it.k0;
+    DQ_LOAD(it.k0, it.kend) DQ_WRITE(0)
+    bool has_next = it.advance();
+    int nk0 = it.k0;
+    if (has_next) DQ_LOAD(it.k0, it.kend)
+    __syncthreads();
+    int cur = 0;
     while (true) {
-      const bool has_next = it.advance();
-      if (has_next) stage_load(it.k0, it.kend);
-      f32x16 X[2], DP[2];
+      bool has_next2 = false;
+      if (has_next) {
+        DQ_WRITE(cur ^ 1)
+        has_next2 = it.advance();
+        if (has_next2) DQ_LOAD(it.k0, it.kend)
+      }
+      const char* Ks = smem + cur * (2 * TILE_BYTES + SE_BYTES); const char* Vs = Ks + TILE_BYTES;
+      const int* se_s = reinterpret_cast<const int*>(Ks + 2 * TILE_BYTES);
+      // one 32-key block at a time keeps S^T/dP^T at 32 live accumulators (2 waves per SIMD need <= 256 registers)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
+        f32x16 X, DP;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) { X[kb][g] = 0.f; DP[kb][g] = 0.f; }
+        for (int g = 0; g < 16; ++g) { X[g] = 0.f; DP[g] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-          X[kb] = T::mma(row_frag<v8>(Ks, 32 * kb + r, 2 * s + h), qf[s], X[kb]);
-          DP[kb] = T::mma(row_frag<v8>(Vs, 32 * kb + r, 2 * s + h), dof[s], DP[kb]);
+          X = T::mma(row_frag<v8>(Ks, 32 * kb + r, 2 * s + h), qf[s], X);
+          DP = T::mma(row_frag<v8>(Vs, 32 * kb + r, 2 * s + h), dof[s], DP);
         }
-      }
-      // dS^T = P ∘ (dP − delta) · scale   (always masked: cheap next to 48 MFMAs, and exact zeros matter)
+        // dS^T = P ∘ (dP − delta) · scale; always masked (exact zeros matter; 4 LDS reads per block)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int gq = 0; gq < 4; ++gq) {
+          const int kl = 32 * kb + 8 * gq + 4 * h;
+          const int4 se4 = *reinterpret_cast<const int4*>(se_s + kl);
+          const int sev[4] = {se4.x, se4.y, se4.z, se4.w};
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int kl = 32 * kb + 8 * (g >> 2) + 4 * h + (g & 3);
-          const bool ok = (ck0 + kl <= qidx) && (qidx < se_s[kl]);
-          const float pv = ok ? fast_exp2(X[kb][g] * c - lse2) : 0.f;
-          X[kb][g] = pv * (DP[kb][g] - delta) * p.scale;
+          for (int j = 0; j < 4; ++j) {
+            const int g = 4 * gq + j;
+            const bool ok = (ck0 + kl + j <= qidx) && (qidx < sev[j]);
+            const float pv = ok ? fast_exp2(__builtin_fmaf(X[g], c, -lse2)) : 0.f;
+            X[g] = pv * (DP[g] - delta) * p.scale;
+          }
         }
-      // dQ^T[d][q] += K^T · dS^T
+        // dQ^T[d][q] += K^T · dS^T
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const v8 db_ = pack_half<DT>(X[s4 >> 1], s4 & 1);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const v8 db_ = pack_half<DT>(X, s2);
 #pragma unroll
-        for (int db = 0; db < 4; ++db) DQ[db] = T::mma(tr_frag<v8>(Ks, 16 * s4, db, lane), db_, DQ[db]);
+          for (int db = 0; db < 4; ++db) DQ[db] = T::mma(tr_frag<v8>(Ks, 32 * kb + 16 * s2, db, lane), db_, DQ[db]);
+        }
       }
       __syncthreads();
       if (!has_next) break;
-      stage_write(); __syncthreads();
-      ck0 = it.k0;
+      cur ^= 1; ck0 = nk0;
+      has_next = has_next2; nk0 = it.k0;
     }
   }
+#undef DQ_LOAD
+#undef DQ_WRITE
   if (qrow < p.Tq) {
     e* dqp = reinterpret_cast<e*>(p.dq) + (int64_t)qrow * p.dq_st + (int64_t)hq * p.dq_sh;
 #pragma unroll
@@ -376,18 +422,19 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // =================================================================================================
-// backward part 2: dK, dV   (key tile owns the workgroup)
+// backward part 2: dK, dV   (key tile owns the workgroup; one wave per SIMD, 128 accumulators each)
 // =================================================================================================
+constexpr int KV_LDS = 2 * (2 * TILE_BYTES + 512);                 // double-buffered {Q image, dO image, lse[64], delta[64]}
+
 template <int DT>
 __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
   using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 512];
-  char* Qs = smem; char* Ds = smem + TILE_BYTES;
-  float* lse_s = reinterpret_cast<float*>(smem + 2 * TILE_BYTES); float* del_s = lse_s + 64;
+  constexpr int NT = 256, CPT = 4;
+  __shared__ __attribute__((aligned(16))) char smem[KV_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int bid = blockIdx.x;
-  const int kvh = bid % p.Hkv; const int kt = bid / p.Hkv;
+  const int kvh = bid % p.Hkv; const int kt = bid / p.Hkv;           // root-side (heaviest) key tiles come first in packed order
   const int k0 = kt * DTA_KTILE;
   const int kidx = k0 + wave * 32 + r;
   const int kidx_c = kidx < p.Tk ? kidx : p.Tk - 1;
@@ -407,68 +454,73 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) { DK[db][g] = 0.f; DV[db][g] = 0.f; }
 
-  int qbeg = k0 > p.q_offset ? k0 : p.q_offset;                      // packed index of the first query that can see a key here
+  const int qbeg = k0 > p.q_offset ? k0 : p.q_offset;                // packed index of the first query that can see a key here
   int qend = p.ktile_qend ? p.ktile_qend[kt] : q_hi; qend = qend < q_hi ? qend : q_hi;
   const int ntile = qend > qbeg ? (qend - qbeg + 63) / 64 : 0;
   const int total = ntile * p.group;
   const float c = p.scale * LOG2E;
 
-  uint4 qreg[4], dreg[4]; float lreg = 0.f, dlreg = 0.f;
-  auto stage_load = [&](int idx) {
-    const int hg = idx / ntile, ti = idx - hg * ntile;
-    const int hq = kvh * p.group + hg;
-    const int row0 = qbeg + 64 * ti - p.q_offset;
-    const e* qb = reinterpret_cast<const e*>(p.q) + (int64_t)hq * p.q_sh;
-    const e* db = reinterpret_cast<const e*>(p.dout) + (int64_t)hq * p.o_sh;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
-      int qr = row0 + row; qr = qr < p.Tq ? qr : p.Tq - 1;
-      qreg[i] = *reinterpret_cast<const uint4*>(qb + (int64_t)qr * p.q_st + ch * 8);
-      dreg[i] = *reinterpret_cast<const uint4*>(db + (int64_t)qr * p.o_st + ch * 8);
-    }
-    if (tid < 64) { int qr = row0 + tid; qr = qr < p.Tq ? qr : p.Tq - 1; lreg = p.lse_r[(int64_t)qr * p.Hq + hq]; dlreg = p.delta[(int64_t)qr * p.Hq + hq]; }
-  };
-  auto stage_write = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + 256 * i, row = id >> 4, ch = id & 15;
-      *reinterpret_cast<uint4*>(Qs + img_off(row, ch)) = qreg[i];
-      *reinterpret_cast<uint4*>(Ds + img_off(row, ch)) = dreg[i];
-    }
-    if (tid < 64) { lse_s[tid] = lreg; del_s[tid] = dlreg; }
-  };
+  u32x4 qreg[CPT], dreg[CPT]; float lreg = 0.f, dlreg = 0.f;
+#define KV_LOAD(IDX)                                                                                       \
+  { const int hg_ = (IDX) / ntile, ti_ = (IDX) - hg_ * ntile; const int hq_ = kvh * p.group + hg_;         \
+    const int row0_ = qbeg + 64 * ti_ - p.q_offset;                                                        \
+    const e* qb_ = reinterpret_cast<const e*>(p.q) + (int64_t)hq_ * p.q_sh;                                \
+    const e* db_ = reinterpret_cast<const e*>(p.dout) + (int64_t)hq_ * p.o_sh;                             \
+    DTA_STAGE_LOAD(qreg, dreg, qb_, db_, p.q_st, p.o_st, row0_, p.Tq, NT, CPT)                             \
+    if (tid < 64) { int qr_ = row0_ + tid; qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;                              \
+      lreg = p.lse_r[(int64_t)qr_ * p.Hq + hq_]; dlreg = p.delta[(int64_t)qr_ * p.Hq + hq_]; } }
+#define KV_WRITE(B)                                                                                        \
+  { char* base_ = smem + (B) * (2 * TILE_BYTES + 512);                                                     \
+    DTA_STAGE_WRITE(qreg, dreg, base_, base_ + TILE_BYTES, NT, CPT)                                        \
+    if (tid < 64) { reinterpret_cast<float*>(base_ + 2 * TILE_BYTES)[tid] = lreg; reinterpret_cast<float*>(base_ + 2 * TILE_BYTES)[64 + tid] = dlreg; } }
 
   if (total > 0) {
-    stage_load(0); stage_write(); __syncthreads();
+    KV_LOAD(0) KV_WRITE(0)
+    if (total > 1) KV_LOAD(1)
+    __syncthreads();
+    int cur = 0;
     for (int idx = 0; idx < total; ++idx) {
-      const bool has_next = idx + 1 < total;
-      if (has_next) stage_load(idx + 1);
+      if (idx + 1 < total) {
+        KV_WRITE(cur ^ 1)
+        if (idx + 2 < total) KV_LOAD(idx + 2)
+      }
+      const char* Qs = smem + cur * (2 * TILE_BYTES + 512); const char* Ds = Qs + TILE_BYTES;
+      const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * TILE_BYTES); const float* del_s = lse_s + 64;
       const int ti = idx % ntile;
       const int qi0 = qbeg + 64 * ti;                                   // packed index of image row 0
+      f32x16 S[2], DP[2];
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
-        f32x16 S, DP;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) { S[g] = 0.f; DP[g] = 0.f; }
+        for (int g = 0; g < 16; ++g) { S[qb][g] = 0.f; DP[qb][g] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-          S = T::mma(row_frag<v8>(Qs, 32 * qb + r, 2 * s + h), kf[s], S);
-          DP = T::mma(row_frag<v8>(Ds, 32 * qb + r, 2 * s + h), vf[s], DP);
+          S[qb] = T::mma(row_frag<v8>(Qs, 32 * qb + r, 2 * s + h), kf[s], S[qb]);
+          DP[qb] = T::mma(row_frag<v8>(Ds, 32 * qb + r, 2 * s + h), vf[s], DP[qb]);
         }
+      }
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int ql = 32 * qb + 8 * (g >> 2) + 4 * h + (g & 3);
-          const int qi = qi0 + ql;
-          const bool ok = (kidx <= qi) && (qi < se_l);
-          const float pv = ok ? fast_exp2(S[g] * c - lse_s[ql]) : 0.f;
-          S[g] = pv;
-          DP[g] = pv * (DP[g] - del_s[ql]) * p.scale;
+      for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int ql = 32 * qb + 8 * gq + 4 * h;
+          const float4 l4 = *reinterpret_cast<const float4*>(lse_s + ql);
+          const float4 d4 = *reinterpret_cast<const float4*>(del_s + ql);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}; const float dv_[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int g = 4 * gq + j;
+            const int qi = qi0 + ql + j;
+            const bool ok = (kidx <= qi) && (qi < se_l);
+            const float pv = ok ? fast_exp2(__builtin_fmaf(S[qb][g], c, -lv[j])) : 0.f;
+            S[qb][g] = pv;
+            DP[qb][g] = pv * (DP[qb][g] - dv_[j]) * p.scale;
+          }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const v8 pb = pack_half<DT>(S, s2);
-          const v8 sb = pack_half<DT>(DP, s2);
+          const v8 pb = pack_half<DT>(S[qb], s2);
+          const v8 sb = pack_half<DT>(DP[qb], s2);
 #pragma unroll
           for (int db = 0; db < 4; ++db) {
             DV[db] = T::mma(tr_frag<v8>(Ds, 32 * qb + 16 * s2, db, lane), pb, DV[db]);
@@ -477,9 +529,11 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
         }
       }
       __syncthreads();
-      if (has_next) { stage_write(); __syncthreads(); }
+      cur ^= 1;
     }
   }
+#undef KV_LOAD
+#undef KV_WRITE
   if (kidx < p.Tk) {
     e* dkp = reinterpret_cast<e*>(p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
     e* dvp = reinterpret_cast<e*>(p.dv) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
@@ -521,11 +575,17 @@ extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v,
   p.Tq = Tq; p.Tk = Tk; p.q_offset = q_offset; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
   p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.o_st = o_st; p.o_sh = o_sh; p.scale = scale;
   const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
-  dim3 grid(nqt * Hq), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();   // drop a stale error of an earlier, unrelated runtime call
-  if (dtype == DTA_BF16) hipLaunchKernelGGL(tree_attn_fwd_kernel<DTA_BF16>, grid, block, 0, st, p);
-  else hipLaunchKernelGGL(tree_attn_fwd_kernel<DTA_F16>, grid, block, 0, st, p);
+  if (p.group % 2 == 0) {      // two query heads of a kv group share the staged K/V tiles
+    dim3 grid(nqt * Hq / 2), block(512);
+    if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_BF16, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_F16, 2>), grid, block, 0, st, p);
+  } else {
+    dim3 grid(nqt * Hq), block(256);
+    if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_BF16, 1>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_F16, 1>), grid, block, 0, st, p);
+  }
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
 }
 
@@ -553,11 +613,13 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();   // drop a stale error of an earlier, unrelated runtime call
   if ((which & 3) == 0) return DTA_EINVAL;
+  const bool pair = p.group % 2 == 0;
+  const dim3 gq(pair ? nqt * Hq / 2 : nqt * Hq), bq(pair ? 512 : 256);
   if (dtype == DTA_BF16) {
-    if (which & 1) hipLaunchKernelGGL(tree_attn_bwd_dq_kernel<DTA_BF16>, dim3(nqt * Hq), dim3(256), 0, st, p);
+    if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 1>), gq, bq, 0, st, p); }
     if (which & 2) hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_BF16>, dim3(nkt * Hkv), dim3(256), 0, st, p);
   } else {
-    if (which & 1) hipLaunchKernelGGL(tree_attn_bwd_dq_kernel<DTA_F16>, dim3(nqt * Hq), dim3(256), 0, st, p);
+    if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 1>), gq, bq, 0, st, p); }
     if (which & 2) hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_F16>, dim3(nkt * Hkv), dim3(256), 0, st, p);
   }
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
