@@ -146,3 +146,96 @@ def meta_from_plan(plan: packing.SegmentPlan, subtree_end: torch.Tensor, device)
     return TreeAttnMeta(T=plan.T, subtree_end=subtree_end,
                         run_ptr=torch.from_numpy(rp).to(device), runs=torch.from_numpy(runs).to(device).contiguous(),
                         ktile_qend=ktile_qend_from(subtree_end))
+
+
+# --------------------------------------------------------------------------------------------------
+# LM head + log-prob / entropy over packed rows (HIP statistics kernels around hipBLASLt GEMMs)
+# --------------------------------------------------------------------------------------------------
+def logprob_entropy_fwd_raw(logits, labels, want_entropy=True, temperature=1.0):
+    """logits [R,V] bf16/f16 (row-contiguous) -> (lse, entropy|None, logprob) fp32 [R]."""
+    _require_cuda(logits)
+    R, V = logits.shape
+    lse = torch.empty(R, dtype=torch.float32, device=logits.device)
+    ent = torch.empty_like(lse) if want_entropy else None
+    lp = torch.empty_like(lse) if labels is not None else None
+    check(lib().dta_logprob_entropy_fwd(ptr(logits), ptr(labels), ptr(lse), ptr(ent), ptr(lp), R, V, logits.stride(0),
+                                        float(temperature), _DT[logits.dtype], _stream()), "dta_logprob_entropy_fwd")
+    return lse, ent, lp
+
+
+def logprob_entropy_bwd_raw(logits, labels, lse, ent, g_lp, g_extra, g_ent, temperature=1.0):
+    """Overwrites `logits` with dLoss/dlogits."""
+    R, V = logits.shape
+    check(lib().dta_logprob_entropy_bwd(ptr(logits), ptr(labels), ptr(lse), ptr(ent), ptr(g_lp), ptr(g_extra), ptr(g_ent), R, V,
+                                        logits.stride(0), float(temperature), _DT[logits.dtype], _stream()), "dta_logprob_entropy_bwd")
+    return logits
+
+
+class _HeadRows(torch.autograd.Function):
+    """(lp_next [T], lp_fork [F], ent [T]) from hidden rows: lp_next[r] = log p(next_tok[r] | row r),
+    lp_fork[f] = log p(fork_tok[f] | row fork_rows[f]).  Rows are processed `chunk` at a time; the
+    [chunk, V] logits are kept for backward when they fit `keep_bytes`, else recomputed."""
+
+    @staticmethod
+    def forward(ctx, h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes):
+        T = h.shape[0]
+        dev = h.device
+        V = W.shape[0]
+        keep = T * V * h.element_size() <= keep_bytes
+        lse = torch.empty(T, dtype=torch.float32, device=dev)
+        ent = torch.empty(T, dtype=torch.float32, device=dev) if want_entropy else None
+        lp_next = torch.empty(T, dtype=torch.float32, device=dev)
+        lp_fork = torch.empty(fork_rows.numel(), dtype=torch.float32, device=dev)
+        kept = []
+        for ci, a in enumerate(range(0, T, chunk)):
+            b = min(a + chunk, T)
+            logits = torch.mm(h[a:b], W.t())
+            l, e, p = logprob_entropy_fwd_raw(logits, next_tok[a:b], want_entropy)
+            lse[a:b] = l; lp_next[a:b] = p
+            if want_entropy:
+                ent[a:b] = e
+            f0, f1 = fork_bounds[ci], fork_bounds[ci + 1]
+            if f1 > f0:
+                lp_fork[f0:f1] = logits[fork_rows[f0:f1] - a, fork_tok[f0:f1]].float() - l[fork_rows[f0:f1] - a]
+            if keep:
+                kept.append(logits)
+        ctx.save_for_backward(h, W, next_tok, fork_rows, fork_tok, lse, ent if want_entropy else lse)
+        ctx.kept, ctx.chunk, ctx.fork_bounds, ctx.want_entropy = kept, chunk, fork_bounds, want_entropy
+        return lp_next, lp_fork, (ent if want_entropy else lse.new_zeros(0))
+
+    @staticmethod
+    def backward(ctx, g_next, g_fork, g_ent):
+        h, W, next_tok, fork_rows, fork_tok, lse, ent = ctx.saved_tensors
+        T = h.shape[0]
+        chunk, fb = ctx.chunk, ctx.fork_bounds
+        g_next = g_next.contiguous().float()
+        g_ent = g_ent.contiguous().float() if ctx.want_entropy else None
+        g_fork = g_fork.contiguous().float()
+        g_extra = None
+        if fork_rows.numel():
+            g_extra = torch.zeros(T, dtype=torch.float32, device=h.device).index_add_(0, fork_rows, g_fork)
+        dh = torch.empty_like(h)
+        dW = torch.zeros(W.shape, dtype=torch.float32, device=W.device)
+        for ci, a in enumerate(range(0, T, chunk)):
+            b = min(a + chunk, T)
+            logits = ctx.kept[ci] if ctx.kept else torch.mm(h[a:b], W.t())
+            logprob_entropy_bwd_raw(logits, next_tok[a:b], lse[a:b], ent[a:b] if ctx.want_entropy else None, g_next[a:b],
+                                    g_extra[a:b] if g_extra is not None else None, g_ent[a:b] if ctx.want_entropy else None)
+            f0, f1 = fb[ci], fb[ci + 1]
+            if f1 > f0:
+                logits.index_put_((fork_rows[f0:f1] - a, fork_tok[f0:f1]), g_fork[f0:f1].to(logits.dtype), accumulate=True)
+            torch.mm(logits, W, out=dh[a:b])
+            dW += torch.mm(logits.t(), h[a:b])
+            if ctx.kept:
+                ctx.kept[ci] = None
+        return dh, dW.to(W.dtype), None, None, None, None, None, None, None
+
+
+def lm_head_rows(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes=None):
+    """See _HeadRows.  `fork_bounds[c] .. fork_bounds[c+1]` = the forks whose row lies in chunk c (host list)."""
+    _require_cuda(h, W)
+    if keep_bytes is None:
+        free, _ = torch.cuda.mem_get_info(h.device)
+        keep_bytes = free // 4
+    lp_next, lp_fork, ent = _HeadRows.apply(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes)
+    return lp_next, lp_fork, (ent if want_entropy else None)

@@ -51,23 +51,14 @@ def _get_forkpos(lens, lcp_lens, block_size: Optional[int]) -> list:
 # --------------------------------------------------------------------------------------------------
 # LM head + logprob/entropy over packed rows
 # --------------------------------------------------------------------------------------------------
-def _head_chunk(h_rows, W, next_tok, fork_rows, fork_tok, want_entropy: bool):
-    logits = torch.nn.functional.linear(h_rows, W)
-    lp_all = torch.log_softmax(logits.float(), dim=-1)
-    ent = -(lp_all.exp() * lp_all).sum(-1) if want_entropy else lp_all.new_zeros(())
-    lp_next = lp_all.gather(-1, next_tok[:, None]).squeeze(-1)
-    lp_fork = lp_all[fork_rows, fork_tok] if fork_rows.numel() else lp_all.new_zeros(0)
-    return lp_next, lp_fork, ent
-
-
 def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tensor, parent: torch.Tensor,
                            want_entropy: bool, chunk: int = 2048, fork_child: Optional[np.ndarray] = None,
                            fork_parent: Optional[np.ndarray] = None):
     """lp[t] = log softmax(h[parent[t]] Wᵀ)[tokens[t]] (0 for roots), ent[t] = H(softmax(h[t] Wᵀ)); fp32.
-    Rows are processed `chunk` at a time and recomputed in backward, so at most one [chunk, V] block
-    of logits is alive (vocab_parallel.py:13-27 arithmetic; tte:190-193, 256-261, 361-372 call sites).
+    The arithmetic (vocab_parallel.py:13-27; call sites tte:190-193, 256-261, 361-372) runs in
+    `ops.lm_head_rows`: hipBLASLt logits GEMM per row chunk + the HIP statistics kernels; at most one
+    [chunk, V] block of fp32-free, model-dtype logits per chunk is ever alive.
     `fork_child`/`fork_parent`: host lists of the tokens whose parent is not the preceding packed token."""
-    from torch.utils.checkpoint import checkpoint
     T = h.shape[0]
     dev = h.device
     if fork_child is None:
@@ -78,25 +69,14 @@ def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tenso
     fp_dev = torch.from_numpy(fork_parent).to(dev)
     ftok = tokens[fc_dev] if fork_child.size else tokens.new_zeros(0)
     nxt = torch.cat([tokens[1:], tokens.new_zeros(1)])
-    lp_next_parts, ent_parts, lp_fork_parts = [], [], []
-    for a in range(0, T, chunk):
-        b = min(a + chunk, T)
-        f0, f1 = np.searchsorted(fork_parent, [a, b])
-        args = (h[a:b], W, nxt[a:b], fp_dev[f0:f1] - a, ftok[f0:f1], want_entropy)
-        if torch.is_grad_enabled() and h.requires_grad:
-            lp_next, lp_fork, ent = checkpoint(_head_chunk, *args, use_reentrant=False)
-        else:
-            lp_next, lp_fork, ent = _head_chunk(*args)
-        lp_next_parts.append(lp_next); lp_fork_parts.append(lp_fork)
-        if want_entropy:
-            ent_parts.append(ent)
-    lp_next = torch.cat(lp_next_parts)                       # lp_next[r] = log p(tokens[r+1] | node r)
-    chain = torch.zeros(T, dtype=torch.bool, device=dev)
+    bounds = np.searchsorted(fork_parent, np.arange(0, T + chunk, chunk)).tolist()
+    lp_next, lp_fork, ent = ops.lm_head_rows(h, W, nxt, fp_dev, ftok, bounds, want_entropy, chunk)
+    chain = torch.zeros(T, dtype=torch.bool, device=dev)           # lp_next[r] = log p(tokens[r+1] | node r)
     chain[1:] = parent[1:] == torch.arange(0, T - 1, device=dev, dtype=parent.dtype)
     lp = torch.cat([lp_next.new_zeros(1), lp_next[:-1]]) * chain
     if fork_child.size:
-        lp = lp.index_copy(0, fc_dev, torch.cat(lp_fork_parts))
-    return lp, (torch.cat(ent_parts) if want_entropy else None)
+        lp = lp.index_copy(0, fc_dev, lp_fork)
+    return lp, ent
 
 
 # --------------------------------------------------------------------------------------------------

@@ -130,6 +130,19 @@ int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v, const void
                          float scale, int32_t dtype, int32_t accumulate,
                          int32_t which /* bit0: delta+dq launch, bit1: dk/dv launch (needs delta) */, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Log-prob / entropy over vocabulary rows (HBM-bound).  logits: [R, V] bf16/f16 with row_stride
+ * elements between rows.  fwd writes (fp32) lse[r] = ln sum_j exp(x_j/T), entropy[r] (may be NULL) and
+ * logprob[r] = x[labels[r]]/T - lse[r] (may be NULL).  bwd OVERWRITES logits with dLoss/dlogits given
+ * g_logprob[r] (for labels[r]), g_extra[r] (sum of the gradients of any further log-probs picked from
+ * row r: a fork node has one per child; their one-hot terms are added by the caller) and g_entropy[r].
+ * Replaces vocab_parallel.py:13-27 (_gather_logprobs[_entropy]) and its autograd backward.  */
+int dta_logprob_entropy_fwd(const void* logits, const int64_t* labels, float* lse, float* entropy, float* logprob,
+                            int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream);
+int dta_logprob_entropy_bwd(void* logits_inout, const int64_t* labels, const float* lse, const float* entropy,
+                            const float* g_logprob, const float* g_extra, const float* g_entropy,
+                            int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,8 +56,18 @@ def _cpu_attention(q, k, v, meta, scale=None):
     return attn_oracle.tree_attention(q, k, v, se, scale)[0]
 
 
+def _cpu_lm_head_rows(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes=None):
+    """Plain-torch stand-in of ops.lm_head_rows (fp32 log-softmax over the full rows)."""
+    lp_all = torch.log_softmax(torch.nn.functional.linear(h, W).float(), dim=-1)
+    ent = -(lp_all.exp() * lp_all).sum(-1) if want_entropy else None
+    lp_next = lp_all.gather(-1, next_tok[:, None]).squeeze(-1)
+    lp_fork = lp_all[fork_rows, fork_tok] if fork_rows.numel() else lp_all.new_zeros(0)
+    return lp_next, lp_fork, ent
+
+
 def install(monkeypatch):
     from dynamictreeattn_amd import ops, token_trie, tree_training_engine
     monkeypatch.setattr(token_trie, "_device_trie_arrays", _cpu_trie_arrays)
     monkeypatch.setattr(tree_training_engine._PackedTrie, "_expand", _cpu_expand)
     monkeypatch.setattr(ops, "tree_attention", _cpu_attention)
+    monkeypatch.setattr(ops, "lm_head_rows", _cpu_lm_head_rows)
