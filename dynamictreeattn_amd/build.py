@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdta_mi355x.so")
-SOURCES = ["tree_attn.hip", "trie_kernels.hip", "logprob_kernels.hip"]
+SOURCES = ["tree_attn.hip", "trie_kernels.hip", "logprob_kernels.hip", "elementwise_kernels.hip"]
 
 
 def _stale() -> bool:

@@ -1,0 +1,321 @@
+// Fused row kernels of the decoder layer for gfx950 — HBM-bound, 16-byte accesses, fp32 math.
+//   dta_rmsnorm_fwd/bwd        y = w · cast(x · rsqrt(mean(x²)+eps))                 (Qwen3RMSNorm arithmetic)
+//   dta_qk_norm_rope_fwd/bwd   per (token, head) of 128: optional RMSNorm, then RoPE at position = trie depth
+//   dta_swiglu_fwd/bwd         y = cast(silu(g)) · u
+// These replace ~40 torch elementwise launches per layer (fp32 up-casts included) that made 28 % of the
+// first profiled step (profiles/r1_v0_bench_kernel_stats.csv).  Reference call sites: the model call of
+// tree_training_engine.py:182-186, 248-252, 351-353 (third-party transformers Qwen3 layers).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dta.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <int DT> struct ETy;
+template <> struct ETy<DTA_BF16> { using e = __bf16; using v8 = bf16x8; };
+template <> struct ETy<DTA_F16> { using e = _Float16; using v8 = f16x8; };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm over rows of H (H % 8 == 0, H <= 8192).  One wave per row, 4 rows per workgroup, grid-stride.
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_, void* __restrict__ y_,
+                                                          float* __restrict__ rstd, int R, int H, float eps) {
+  using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const e* w = reinterpret_cast<const e*>(w_);
+  const int nv = H >> 3;
+  for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+    const e* x = reinterpret_cast<const e*>(x_) + (int64_t)row * H;
+    e* y = reinterpret_cast<e*>(y_) + (int64_t)row * H;
+    float ss = 0.f;
+    for (int i = lane; i < nv; i += 64) {
+      const v8 v = *reinterpret_cast<const v8*>(x + 8 * i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; ss = __builtin_fmaf(f, f, ss); }
+    }
+    ss = wave_sum(ss);
+    const float r = __builtin_amdgcn_rsqf(ss / (float)H + eps);
+    if (lane == 0) rstd[row] = r;
+    for (int i = lane; i < nv; i += 64) {
+      const v8 v = *reinterpret_cast<const v8*>(x + 8 * i);
+      const v8 wv = *reinterpret_cast<const v8*>(w + 8 * i);
+      v8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const e t = (e)((float)v[j] * r); o[j] = (e)((float)wv[j] * (float)t); }
+      *reinterpret_cast<v8*>(y + 8 * i) = o;
+    }
+  }
+}
+
+// dx = r·(dt − t̂·mean(dt·t̂)), dt = dy·w, t̂ = x·r ;  dw partial per workgroup: Σ_rows dy·t̂  (H <= 4096 -> <= 8 x v8 per lane)
+template <int DT>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_, const void* __restrict__ dy_,
+                                                          const float* __restrict__ rstd, void* __restrict__ dx_, float* __restrict__ dw_part,
+                                                          int R, int H) {
+  using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
+  __shared__ float red[4 * 64 * 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const e* w = reinterpret_cast<const e*>(w_);
+  const int nv = H >> 3;
+  const int per_lane = (nv + 63) >> 6;                      // <= 8
+  float acc[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[a][j] = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+    const e* x = reinterpret_cast<const e*>(x_) + (int64_t)row * H;
+    const e* dy = reinterpret_cast<const e*>(dy_) + (int64_t)row * H;
+    e* dx = reinterpret_cast<e*>(dx_) + (int64_t)row * H;
+    const float r = rstd[row];
+    float dot = 0.f;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int i = lane + 64 * a;
+      if (a < per_lane && i < nv) {
+        const v8 v = *reinterpret_cast<const v8*>(x + 8 * i); const v8 g = *reinterpret_cast<const v8*>(dy + 8 * i);
+        const v8 wv = *reinterpret_cast<const v8*>(w + 8 * i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = (float)v[j] * r; const float gg = (float)g[j]; dot = __builtin_fmaf(gg * (float)wv[j], t, dot); acc[a][j] = __builtin_fmaf(gg, t, acc[a][j]); }
+      }
+    }
+    dot = wave_sum(dot) / (float)H;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int i = lane + 64 * a;
+      if (a < per_lane && i < nv) {
+        const v8 v = *reinterpret_cast<const v8*>(x + 8 * i); const v8 g = *reinterpret_cast<const v8*>(dy + 8 * i);
+        const v8 wv = *reinterpret_cast<const v8*>(w + 8 * i);
+        v8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = (float)v[j] * r; o[j] = (e)(r * ((float)g[j] * (float)wv[j] - t * dot)); }
+        *reinterpret_cast<v8*>(dx + 8 * i) = o;
+      }
+    }
+  }
+  // reduce the 4 waves' dw partials through LDS, one v8-group at a time
+  float* out = dw_part + (int64_t)blockIdx.x * H;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {                              // static register index; `a < per_lane` is block-uniform
+    if (a < per_lane) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[(wave * 64 + lane) * 8 + j] = acc[a][j];
+      __syncthreads();
+      if (wave == 0) {
+        const int i = lane + 64 * a;
+        if (i < nv) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) out[8 * i + j] = red[lane * 8 + j] + red[(64 + lane) * 8 + j] + red[(128 + lane) * 8 + j] + red[(192 + lane) * 8 + j];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// q/k head-norm + RoPE.  x: [T, NH, 128]; 16 lanes own one head (8 elements each); a wave = 4 heads.
+// cs: [T, 128] float = {cos[0..63], sin[0..63]} of the token's depth.  w == NULL: RoPE only.
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void qk_norm_rope_fwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_, const float* __restrict__ cs,
+                                                               void* __restrict__ y_, float* __restrict__ rstd, int64_t n_heads_total, int NH,
+                                                               int64_t x_st, float eps) {
+  using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const int64_t hid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);      // global (token, head) index
+  if (hid >= n_heads_total) return;
+  const int64_t tok = hid / NH; const int head = (int)(hid - tok * NH);
+  const e* x = reinterpret_cast<const e*>(x_) + tok * x_st + (int64_t)head * 128 + 8 * sub;
+  e* y = reinterpret_cast<e*>(y_) + hid * 128 + 8 * sub;
+  const v8 v = *reinterpret_cast<const v8*>(x);
+  float a[8];
+  if (w_) {
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; ss = __builtin_fmaf(f, f, ss); }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float r = __builtin_amdgcn_rsqf(ss * (1.f / 128.f) + eps);
+    if (sub == 0) rstd[hid] = r;
+    const v8 wv = *reinterpret_cast<const v8*>(reinterpret_cast<const e*>(w_) + 8 * sub);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const e t = (e)((float)v[j] * r); a[j] = (float)(e)((float)wv[j] * (float)t); }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (float)v[j];
+  }
+  // rotate_half partner: element i <-> i ± 64  == lane sub ^ 8 of the same head group
+  const float* c = cs + tok * 128 + 8 * (sub & 7);
+  v8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float other = __shfl_xor(a[j], 8);
+    const float cj = c[j], sj = c[64 + j];
+    o[j] = (e)(sub < 8 ? a[j] * cj - other * sj : a[j] * cj + other * sj);
+  }
+  *reinterpret_cast<v8*>(y) = o;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_, const float* __restrict__ cs,
+                                                               const void* __restrict__ dy_, const float* __restrict__ rstd,
+                                                               void* __restrict__ dx_, float* __restrict__ dw_part, int64_t n_heads_total, int NH,
+                                                               int64_t x_st, int64_t dy_st_t, int64_t dy_st_h) {
+  using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
+  __shared__ float red[256 * 8];
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int64_t base = (int64_t)blockIdx.x * 16; base < n_heads_total; base += (int64_t)gridDim.x * 16) {
+    const int64_t hid = base + (threadIdx.x >> 6) * 4 + (lane >> 4);
+    const bool live = hid < n_heads_total;
+    const int64_t hc = live ? hid : n_heads_total - 1;
+    const int64_t tok = hc / NH; const int head = (int)(hc - tok * NH);
+    const e* dy = reinterpret_cast<const e*>(dy_) + tok * dy_st_t + (int64_t)head * dy_st_h + 8 * sub;
+    const v8 g = *reinterpret_cast<const v8*>(dy);
+    const float* c = cs + tok * 128 + 8 * (sub & 7);
+    float da[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gj = (float)g[j];
+      const float other = __shfl_xor(gj, 8);
+      const float cj = c[j], sj = c[64 + j];
+      da[j] = sub < 8 ? gj * cj + other * sj : gj * cj - other * sj;
+    }
+    e* dx = reinterpret_cast<e*>(dx_) + hc * 128 + 8 * sub;
+    v8 o;
+    if (w_) {
+      const e* x = reinterpret_cast<const e*>(x_) + tok * x_st + (int64_t)head * 128 + 8 * sub;
+      const v8 v = *reinterpret_cast<const v8*>(x);
+      const v8 wv = *reinterpret_cast<const v8*>(reinterpret_cast<const e*>(w_) + 8 * sub);
+      const float r = rstd[hc];
+      float dot = 0.f, t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { t[j] = (float)v[j] * r; dot = __builtin_fmaf(da[j] * (float)wv[j], t[j], dot); if (live) acc[j] = __builtin_fmaf(da[j], t[j], acc[j]); }
+#pragma unroll
+      for (int o2 = 8; o2 > 0; o2 >>= 1) dot += __shfl_xor(dot, o2);
+      dot *= (1.f / 128.f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (e)(r * (da[j] * (float)wv[j] - t[j] * dot));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (e)da[j];
+    }
+    if (live) *reinterpret_cast<v8*>(dx) = o;
+  }
+  if (w_) {                                              // dw partial [gridDim.x, 128]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int s = threadIdx.x >> 3, j = threadIdx.x & 7;                   // element 8*s + j
+      float t = 0.f;
+      for (int g2 = 0; g2 < 16; ++g2) t += red[(g2 * 16 + s) * 8 + j];
+      dw_part[(int64_t)blockIdx.x * 128 + threadIdx.x] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const void* __restrict__ g_, const void* __restrict__ u_, void* __restrict__ y_, int64_t n8) {
+  using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const v8 g = reinterpret_cast<const v8*>(g_)[i]; const v8 u = reinterpret_cast<const v8*>(u_)[i];
+    v8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float x = (float)g[j]; const e s = (e)(x / (1.f + __expf(-x))); o[j] = (e)((float)s * (float)u[j]); }
+    reinterpret_cast<v8*>(y_)[i] = o;
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const void* __restrict__ g_, const void* __restrict__ u_, const void* __restrict__ dy_,
+                                                         void* __restrict__ dg_, void* __restrict__ du_, int64_t n8) {
+  using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const v8 g = reinterpret_cast<const v8*>(g_)[i]; const v8 u = reinterpret_cast<const v8*>(u_)[i]; const v8 dy = reinterpret_cast<const v8*>(dy_)[i];
+    v8 dg, du;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = (float)g[j], sg = 1.f / (1.f + __expf(-x)), d = (float)dy[j];
+      du[j] = (e)(d * x * sg);
+      dg[j] = (e)(d * (float)u[j] * sg * (1.f + x * (1.f - sg)));
+    }
+    reinterpret_cast<v8*>(dg_)[i] = dg; reinterpret_cast<v8*>(du_)[i] = du;
+  }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int row_blocks(int64_t rows, int per_block, int cap) { int64_t b = (rows + per_block - 1) / per_block; return (int)(b < cap ? (b > 0 ? b : 1) : cap); }
+
+}  // namespace
+
+#define DTA_DISPATCH(KERNEL, GRID, ...)                                                                    \
+  do { hipStream_t st_ = static_cast<hipStream_t>(stream); (void)hipGetLastError();                       \
+       if (dtype == DTA_BF16) hipLaunchKernelGGL(KERNEL<DTA_BF16>, dim3(GRID), dim3(256), 0, st_, __VA_ARGS__); \
+       else hipLaunchKernelGGL(KERNEL<DTA_F16>, dim3(GRID), dim3(256), 0, st_, __VA_ARGS__);               \
+       return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH; } while (0)
+
+extern "C" int dta_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int32_t R, int32_t H, float eps, int32_t dtype, void* stream) {
+  if (!x || !w || !y || !rstd || R <= 0 || H <= 0) return DTA_EINVAL;
+  if ((dtype != DTA_BF16 && dtype != DTA_F16) || H % 8 || H > 4096) return DTA_EUNSUPPORTED;
+  if (!al16(x) || !al16(w) || !al16(y)) return DTA_EALIGN;
+  DTA_DISPATCH(rmsnorm_fwd_kernel, row_blocks(R, 4, 4096), x, w, y, rstd, R, H, eps);
+}
+
+/* dw_partial: float [dta_rmsnorm_bwd_blocks(R), H]; the caller sums it over dim 0. */
+extern "C" int dta_rmsnorm_bwd_blocks(int32_t R) { return row_blocks(R, 4, 512); }
+extern "C" int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rstd, void* dx, float* dw_partial,
+                               int32_t R, int32_t H, int32_t dtype, void* stream) {
+  if (!x || !w || !dy || !rstd || !dx || !dw_partial || R <= 0 || H <= 0) return DTA_EINVAL;
+  if ((dtype != DTA_BF16 && dtype != DTA_F16) || H % 8 || H > 4096) return DTA_EUNSUPPORTED;
+  if (!al16(x) || !al16(w) || !al16(dy) || !al16(dx)) return DTA_EALIGN;
+  DTA_DISPATCH(rmsnorm_bwd_kernel, row_blocks(R, 4, 512), x, w, dy, rstd, dx, dw_partial, R, H);
+}
+
+extern "C" int dta_qk_norm_rope_fwd(const void* x, const void* w, const float* cos_sin, void* y, float* rstd,
+                                    int32_t T, int32_t NH, int32_t head_dim, int64_t x_stride_t, float eps, int32_t dtype, void* stream) {
+  if (!x || !cos_sin || !y || T <= 0 || NH <= 0 || (w && !rstd)) return DTA_EINVAL;
+  if ((dtype != DTA_BF16 && dtype != DTA_F16) || head_dim != 128) return DTA_EUNSUPPORTED;
+  if (!al16(x) || !al16(y) || (w && !al16(w)) || x_stride_t % 8) return DTA_EALIGN;
+  const int64_t n = (int64_t)T * NH;
+  DTA_DISPATCH(qk_norm_rope_fwd_kernel, (unsigned)((n + 15) / 16), x, w, cos_sin, y, rstd, n, NH, x_stride_t, eps);
+}
+
+/* dw_partial: float [dta_qk_norm_rope_bwd_blocks(T*NH), 128] (ignored when w == NULL). */
+extern "C" int dta_qk_norm_rope_bwd_blocks(int64_t n_heads_total) { return row_blocks(n_heads_total, 16, 1024); }
+extern "C" int dta_qk_norm_rope_bwd(const void* x, const void* w, const float* cos_sin, const void* dy, const float* rstd,
+                                    void* dx, float* dw_partial, int32_t T, int32_t NH, int32_t head_dim,
+                                    int64_t x_stride_t, int64_t dy_stride_t, int64_t dy_stride_h, int32_t dtype, void* stream) {
+  if (!cos_sin || !dy || !dx || T <= 0 || NH <= 0 || (w && (!x || !rstd || !dw_partial))) return DTA_EINVAL;
+  if ((dtype != DTA_BF16 && dtype != DTA_F16) || head_dim != 128) return DTA_EUNSUPPORTED;
+  if (!al16(dy) || !al16(dx) || (w && (!al16(w) || !al16(x))) || x_stride_t % 8 || dy_stride_t % 8 || dy_stride_h % 8) return DTA_EALIGN;
+  const int64_t n = (int64_t)T * NH;
+  DTA_DISPATCH(qk_norm_rope_bwd_kernel, row_blocks(n, 16, 1024), x, w, cos_sin, dy, rstd, dx, dw_partial, n, NH, x_stride_t, dy_stride_t, dy_stride_h);
+}
+
+extern "C" int dta_swiglu_fwd(const void* gate, const void* up, void* y, int64_t n, int32_t dtype, void* stream) {
+  if (!gate || !up || !y || n <= 0) return DTA_EINVAL;
+  if ((dtype != DTA_BF16 && dtype != DTA_F16) || n % 8) return DTA_EUNSUPPORTED;
+  if (!al16(gate) || !al16(up) || !al16(y)) return DTA_EALIGN;
+  DTA_DISPATCH(swiglu_fwd_kernel, row_blocks(n / 8, 256, 4096), gate, up, y, n / 8);
+}
+
+extern "C" int dta_swiglu_bwd(const void* gate, const void* up, const void* dy, void* dgate, void* dup, int64_t n, int32_t dtype, void* stream) {
+  if (!gate || !up || !dy || !dgate || !dup || n <= 0) return DTA_EINVAL;
+  if ((dtype != DTA_BF16 && dtype != DTA_F16) || n % 8) return DTA_EUNSUPPORTED;
+  if (!al16(gate) || !al16(up) || !al16(dy) || !al16(dgate) || !al16(dup)) return DTA_EALIGN;
+  DTA_DISPATCH(swiglu_bwd_kernel, row_blocks(n / 8, 256, 4096), gate, up, dy, dgate, dup, n / 8);
+}

@@ -109,59 +109,40 @@ def _cfg_of(model):
     return c.num_attention_heads, c.num_key_value_heads, D, float(getattr(c, "rms_norm_eps", 1e-6)), float(theta)
 
 
-def _rms(x, w, eps):
-    # same arithmetic as the reference's model: normalise in fp32, round to the model dtype, then scale
-    xf = x.float()
-    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
-    return w * xf.to(x.dtype)
-
-
-def rope_tables(depth: torch.Tensor, D: int, theta: float, dtype):
-    inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.float32, device=depth.device) / D))
-    ang = depth.float()[:, None] * inv[None, :]
-    ang = torch.cat([ang, ang], dim=-1)
-    return ang.cos().to(dtype)[:, None, :], ang.sin().to(dtype)[:, None, :]
-
-
-def _rot(x, cos, sin):
-    h = x.shape[-1] // 2
-    return x * cos + torch.cat([-x[..., h:], x[..., :h]], dim=-1) * sin
-
-
-def _layer_forward(layer, x, cos, sin, meta, Hq, Hkv, D, eps, attn_fn):
+def _layer_forward(layer, x, cos_sin, meta, Hq, Hkv, D, eps):
+    """One decoder layer over the packed rows: hipBLASLt GEMMs through torch; everything between them
+    is a HIP kernel of this package (ops.rms_norm, ops.qk_norm_rope, ops.tree_attention, ops.swiglu)."""
     T = x.shape[0]
     a = layer.self_attn
-    h = _rms(x, layer.input_layernorm.weight, eps)
+    h = ops.rms_norm(x, layer.input_layernorm.weight, eps)
     q = F.linear(h, a.q_proj.weight, getattr(a.q_proj, "bias", None)).view(T, Hq, D)
     k = F.linear(h, a.k_proj.weight, getattr(a.k_proj, "bias", None)).view(T, Hkv, D)
     v = F.linear(h, a.v_proj.weight, getattr(a.v_proj, "bias", None)).view(T, Hkv, D)
-    if hasattr(a, "q_norm"):
-        q = _rms(q, a.q_norm.weight, eps); k = _rms(k, a.k_norm.weight, eps)
-    q = _rot(q, cos, sin); k = _rot(k, cos, sin)
-    o = attn_fn(q, k, v, meta)
+    qn = getattr(a, "q_norm", None); kn = getattr(a, "k_norm", None)
+    q = ops.qk_norm_rope(q, qn.weight if qn is not None else None, cos_sin, eps)
+    k = ops.qk_norm_rope(k, kn.weight if kn is not None else None, cos_sin, eps)
+    o = ops.tree_attention(q, k, v, meta)
     x = x + F.linear(o.reshape(T, Hq * D), a.o_proj.weight)
-    h = _rms(x, layer.post_attention_layernorm.weight, eps)
+    h = ops.rms_norm(x, layer.post_attention_layernorm.weight, eps)
     m = layer.mlp
-    x = x + F.linear(F.silu(F.linear(h, m.gate_proj.weight)) * F.linear(h, m.up_proj.weight), m.down_proj.weight)
+    x = x + F.linear(ops.swiglu(F.linear(h, m.gate_proj.weight), F.linear(h, m.up_proj.weight)), m.down_proj.weight)
     return x
 
 
-def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta, checkpoint_layers: bool = False,
-                         attn_fn=None) -> torch.Tensor:
+def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta, checkpoint_layers: bool = False) -> torch.Tensor:
     """Final-norm hidden states [T, hidden] of the packed tokens.  `model` is a Qwen3TreeLM or an HF
-    Qwen2/Qwen3 *ForCausalLM (duck-typed).  `attn_fn(q,k,v,meta)` defaults to the HIP operator."""
-    attn_fn = attn_fn or ops.tree_attention
+    Qwen2/Qwen3 *ForCausalLM (duck-typed)."""
     Hq, Hkv, D, eps, theta = _cfg_of(model)
     body = model.model
     x = F.embedding(tokens, body.embed_tokens.weight)
-    cos, sin = rope_tables(depth, D, theta, x.dtype)
+    cos_sin = ops.rope_cos_sin(depth, D, theta)
     for layer in body.layers:
         if checkpoint_layers and torch.is_grad_enabled():
             from torch.utils.checkpoint import checkpoint
-            x = checkpoint(_layer_forward, layer, x, cos, sin, meta, Hq, Hkv, D, eps, attn_fn, use_reentrant=False)
+            x = checkpoint(_layer_forward, layer, x, cos_sin, meta, Hq, Hkv, D, eps, use_reentrant=False)
         else:
-            x = _layer_forward(layer, x, cos, sin, meta, Hq, Hkv, D, eps, attn_fn)
-    return _rms(x, body.norm.weight, eps)
+            x = _layer_forward(layer, x, cos_sin, meta, Hq, Hkv, D, eps)
+    return ops.rms_norm(x, body.norm.weight, eps)
 
 
 def head_weight(model) -> torch.Tensor:

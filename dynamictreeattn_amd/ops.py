@@ -239,3 +239,99 @@ def lm_head_rows(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy,
         keep_bytes = free // 4
     lp_next, lp_fork, ent = _HeadRows.apply(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes)
     return lp_next, lp_fork, (ent if want_entropy else None)
+
+
+# --------------------------------------------------------------------------------------------------
+# Fused decoder-layer row kernels (RMSNorm, head-norm + RoPE, SwiGLU)
+# --------------------------------------------------------------------------------------------------
+class _RMSNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        _require_cuda(x, w)
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        R, H = x2.shape
+        y = torch.empty_like(x2)
+        rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+        check(lib().dta_rmsnorm_fwd(ptr(x2), ptr(w), ptr(y), ptr(rstd), R, H, float(eps), _DT[x.dtype], _stream()), "dta_rmsnorm_fwd")
+        ctx.save_for_backward(x2, w, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, rstd = ctx.saved_tensors
+        R, H = x2.shape
+        dy2 = dy.contiguous().view(R, H)
+        dx = torch.empty_like(x2)
+        part = torch.empty(lib().dta_rmsnorm_bwd_blocks(R), H, dtype=torch.float32, device=x2.device)
+        check(lib().dta_rmsnorm_bwd(ptr(x2), ptr(w), ptr(dy2), ptr(rstd), ptr(dx), ptr(part), R, H, _DT[x2.dtype], _stream()), "dta_rmsnorm_bwd")
+        return dx.view(dy.shape), part.sum(0).to(w.dtype), None
+
+
+def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    return _RMSNorm.apply(x, w, eps)
+
+
+class _QKNormRope(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, cos_sin, eps):
+        _require_cuda(x, cos_sin)
+        T, NH, D = x.shape
+        if x.stride(2) != 1 or x.stride(1) != D:
+            x = x.contiguous()
+        y = torch.empty((T, NH, D), dtype=x.dtype, device=x.device)
+        rstd = torch.empty(T * NH, dtype=torch.float32, device=x.device) if w is not None else None
+        check(lib().dta_qk_norm_rope_fwd(ptr(x), ptr(w), ptr(cos_sin), ptr(y), ptr(rstd), T, NH, D, x.stride(0), float(eps),
+                                         _DT[x.dtype], _stream()), "dta_qk_norm_rope_fwd")
+        ctx.save_for_backward(x, w if w is not None else cos_sin, cos_sin, rstd if rstd is not None else cos_sin)
+        ctx.has_w = w is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, cos_sin, rstd = ctx.saved_tensors
+        T, NH, D = x.shape
+        if dy.stride(2) != 1:
+            dy = dy.contiguous()
+        dx = torch.empty((T, NH, D), dtype=x.dtype, device=x.device)
+        part = None
+        if ctx.has_w:
+            part = torch.empty(lib().dta_qk_norm_rope_bwd_blocks(T * NH), D, dtype=torch.float32, device=x.device)
+        check(lib().dta_qk_norm_rope_bwd(ptr(x), ptr(w) if ctx.has_w else None, ptr(cos_sin), ptr(dy), ptr(rstd) if ctx.has_w else None,
+                                         ptr(dx), ptr(part), T, NH, D, x.stride(0), dy.stride(0), dy.stride(1), _DT[x.dtype], _stream()),
+              "dta_qk_norm_rope_bwd")
+        return dx, (part.sum(0).to(w.dtype) if ctx.has_w else None), None, None
+
+
+def qk_norm_rope(x: torch.Tensor, w: Optional[torch.Tensor], cos_sin: torch.Tensor, eps: float) -> torch.Tensor:
+    """x [T, NH, 128] -> RoPE(RMSNorm_128(x) * w) at the positions encoded in cos_sin [T,128] (fp32)."""
+    return _QKNormRope.apply(x, w, cos_sin, eps)
+
+
+def rope_cos_sin(depth: torch.Tensor, D: int, theta: float) -> torch.Tensor:
+    """fp32 [T, D] table {cos[D/2], sin[D/2]} of position = trie depth (computed once per trie)."""
+    inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.float32, device=depth.device) / D))
+    ang = depth.float()[:, None] * inv[None, :]
+    return torch.cat([ang.cos(), ang.sin()], dim=-1).contiguous()
+
+
+class _SwiGLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, u):
+        _require_cuda(g, u)
+        g = g.contiguous(); u = u.contiguous()
+        y = torch.empty_like(g)
+        check(lib().dta_swiglu_fwd(ptr(g), ptr(u), ptr(y), g.numel(), _DT[g.dtype], _stream()), "dta_swiglu_fwd")
+        ctx.save_for_backward(g, u)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        g, u = ctx.saved_tensors
+        dy = dy.contiguous()
+        dg, du = torch.empty_like(g), torch.empty_like(u)
+        check(lib().dta_swiglu_bwd(ptr(g), ptr(u), ptr(dy), ptr(dg), ptr(du), g.numel(), _DT[g.dtype], _stream()), "dta_swiglu_bwd")
+        return dg, du
+
+
+def swiglu(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    return _SwiGLU.apply(g, u)

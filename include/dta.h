@@ -143,6 +143,27 @@ int dta_logprob_entropy_bwd(void* logits_inout, const int64_t* labels, const flo
                             const float* g_logprob, const float* g_extra, const float* g_entropy,
                             int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused row kernels of the decoder layer (HBM-bound; bf16/f16 storage, fp32 math).  They restate the
+ * arithmetic of the third-party Qwen3 layers the reference calls (tree_training_engine.py:182-186,
+ * 248-252, 351-353): RMSNorm = w * cast(x * rsqrt(mean(x^2)+eps)); rotate-half RoPE at position =
+ * trie depth; SwiGLU = cast(silu(g)) * u.
+ * ------------------------------------------------------------------------------------------- */
+int dta_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int32_t R, int32_t H, float eps, int32_t dtype, void* stream);
+int dta_rmsnorm_bwd_blocks(int32_t R);   /* rows of the dw_partial workspace [blocks, H] (float); caller sums dim 0 */
+int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rstd, void* dx, float* dw_partial,
+                    int32_t R, int32_t H, int32_t dtype, void* stream);
+/* x: [T, NH, 128] with token stride x_stride_t; cos_sin: float [T, 128] = {cos[64], sin[64]} of the token's
+ * depth; y: [T, NH, 128] contiguous; w (head-norm weight [128]) may be NULL = RoPE only. */
+int dta_qk_norm_rope_fwd(const void* x, const void* w, const float* cos_sin, void* y, float* rstd,
+                         int32_t T, int32_t NH, int32_t head_dim, int64_t x_stride_t, float eps, int32_t dtype, void* stream);
+int dta_qk_norm_rope_bwd_blocks(int64_t n_heads_total);   /* rows of dw_partial [blocks, 128] */
+int dta_qk_norm_rope_bwd(const void* x, const void* w, const float* cos_sin, const void* dy, const float* rstd,
+                         void* dx, float* dw_partial, int32_t T, int32_t NH, int32_t head_dim,
+                         int64_t x_stride_t, int64_t dy_stride_t, int64_t dy_stride_h, int32_t dtype, void* stream);
+int dta_swiglu_fwd(const void* gate, const void* up, void* y, int64_t n, int32_t dtype, void* stream);
+int dta_swiglu_bwd(const void* gate, const void* up, const void* dy, void* dgate, void* dup, int64_t n, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

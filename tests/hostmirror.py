@@ -65,9 +65,30 @@ def _cpu_lm_head_rows(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_ent
     return lp_next, lp_fork, ent
 
 
+def _cpu_rms_norm(x, w, eps):
+    xf = x.float()
+    return w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype)
+
+
+def _cpu_qk_norm_rope(x, w, cos_sin, eps):
+    if w is not None:
+        x = _cpu_rms_norm(x, w, eps)
+    half = x.shape[-1] // 2
+    cos = torch.cat([cos_sin[:, :half], cos_sin[:, :half]], -1).to(x.dtype)[:, None, :]
+    sin = torch.cat([cos_sin[:, half:], cos_sin[:, half:]], -1).to(x.dtype)[:, None, :]
+    return x * cos + torch.cat([-x[..., half:], x[..., :half]], -1) * sin
+
+
+def _cpu_swiglu(g, u):
+    return torch.nn.functional.silu(g) * u
+
+
 def install(monkeypatch):
     from dynamictreeattn_amd import ops, token_trie, tree_training_engine
     monkeypatch.setattr(token_trie, "_device_trie_arrays", _cpu_trie_arrays)
     monkeypatch.setattr(tree_training_engine._PackedTrie, "_expand", _cpu_expand)
     monkeypatch.setattr(ops, "tree_attention", _cpu_attention)
     monkeypatch.setattr(ops, "lm_head_rows", _cpu_lm_head_rows)
+    monkeypatch.setattr(ops, "rms_norm", _cpu_rms_norm)
+    monkeypatch.setattr(ops, "qk_norm_rope", _cpu_qk_norm_rope)
+    monkeypatch.setattr(ops, "swiglu", _cpu_swiglu)
