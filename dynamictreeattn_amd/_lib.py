@@ -40,6 +40,9 @@ def lib():
         if not os.path.exists(LIB):
             raise RuntimeError(f"{LIB} is missing: run `python -m dynamictreeattn_amd.build` (hipcc, gfx950). "
                                "There is no CPU fallback for the hot path.")
+        # torch ships its own libamdhip64; it must be resident BEFORE this library so that both resolve
+        # to ONE HIP runtime (otherwise torch's streams/pointers are foreign to our kernels: launches fail).
+        import torch  # noqa: F401
         l = C.CDLL(LIB)
         for name, (args, res) in _PROTOS.items():
             fn = getattr(l, name)
