@@ -25,11 +25,9 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 
-from dynamictreeattn_amd import data_parallel as dp
-from dynamictreeattn_amd import ops, synth
+from dynamictreeattn_amd import dp, ops, synth
 from dynamictreeattn_amd.model import Qwen3TreeLM, make_config
 from dynamictreeattn_amd.token_trie import TokenTrie
-from dynamictreeattn_amd.tree_time_model import TreeTimeModel
 from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine
 
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16 peak, MI355X_MICROARCH.md "Chip-level parameters"
@@ -50,22 +48,6 @@ def build_model(cfg: dict, device, dtype, seed: int = 0):
             else:
                 p.copy_((torch.randn(p.shape, generator=g, device=device, dtype=torch.float32) * 0.02).to(dtype))
     return m.train()
-
-
-def allreduce_grads(model, bucket_elems: int = 1 << 28):
-    """One logical all-reduce(SUM) of every parameter gradient (no averaging: the reference's loss is
-    a plain sum over sequences, tte:396-398), in a few large flat buckets for RCCL over xGMI."""
-    grads = [p.grad for p in model.parameters() if p.grad is not None]
-    i = 0
-    while i < len(grads):
-        chunk, n = [], 0
-        while i < len(grads) and (not chunk or n + grads[i].numel() <= bucket_elems):
-            chunk.append(grads[i]); n += grads[i].numel(); i += 1
-        flat = torch.cat([g.reshape(-1) for g in chunk])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        o = 0
-        for g in chunk:
-            g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
 
 
 def host_threads() -> int:
@@ -157,22 +139,17 @@ def main():
         for r in range(world):
             seqs += synth.as_tensors(synth.tau2(seed=s * world + r, V=V))
         batches.append(seqs)
-    bal_args = types.SimpleNamespace(K=world, mode="backward", block_size=args.block_size)
 
     stats_acc = {"n_tokens": 0, "n_tree_tokens": 0, "pairs": 0}
 
     def step(seqs, timed: bool):
-        if world > 1:
-            bins = dp.LB_by_DFS_and_TM(seqs, TreeTimeModel(), bal_args)
-            mine = [seqs[i] for i in bins[rank]]
-        else:
-            mine = seqs
+        mine = [seqs[i] for i in dp.my_bin(seqs, rank, world, "backward", args.block_size)]
         model.zero_grad(set_to_none=True)
         trie = TokenTrie(mine, [dict(ATTACH) for _ in mine])
         trie.backward_permute()
         loss = engine.backward(model, trie, loss_fn, args.block_size)
         if world > 1:
-            allreduce_grads(model)
+            dp.allreduce_grads(model.parameters())
         if timed:
             st = trie.get_stats("backward", args.block_size)
             stats_acc["n_tokens"] += st["n_tokens"]; stats_acc["n_tree_tokens"] += st["n_tree_tokens"]
