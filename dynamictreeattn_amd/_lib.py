@@ -18,7 +18,7 @@ _PROTOS = {
     "dta_tree_attn_fwd": ([_vp] * 8 + [_i32] * 6 + [_i64] * 3 + [_f32, _i32, _vp], C.c_int),
     "dta_tree_attn_bwd": ([_vp] * 14 + [_i32] * 6 + [_i64] * 5 + [_f32, _i32, _i32, _vp], C.c_int),
     "dta_tree_attn_fwd_ex": ([_vp] * 8 + [_i32] * 6 + [_i64] * 6 + [_f32, _i32, _vp], C.c_int),
-    "dta_tree_attn_bwd_ex": ([_vp] * 14 + [_i32] * 6 + [_i64] * 10 + [_f32, _i32, _i32, _i32, _vp], C.c_int),
+    "dta_tree_attn_bwd_ex": ([_vp] * 14 + [_i32] * 6 + [_i64] * 10 + [_f32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp], C.c_int),
     "dta_logprob_entropy_fwd": ([_vp] * 5 + [_i32, _i32, _i64, _f32, _i32, _vp], C.c_int),
     "dta_logprob_entropy_bwd": ([_vp] * 7 + [_i32, _i32, _i64, _f32, _i32, _vp], C.c_int),
     "dta_rmsnorm_fwd": ([_vp] * 4 + [_i32, _i32, _f32, _i32, _vp], C.c_int),

@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libdta_mi355x.so")
+LIB = os.environ.get("DTA_LIB") or os.path.join(HERE, "libdta_mi355x.so")      # DTA_LIB: diagnostic builds only
 SOURCES = ["tree_attn.hip", "trie_kernels.hip", "logprob_kernels.hip", "elementwise_kernels.hip"]
 
 

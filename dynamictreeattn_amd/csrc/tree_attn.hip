@@ -18,6 +18,7 @@
 // Lane maps used here were verified on hardware by tests/micro/mfma_layout_probe.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/dta.h"
 
 namespace {
@@ -46,6 +47,7 @@ struct AttnParams {
   void *out, *dq, *dk, *dv;
   float *lse_w; const float* lse_r; float* delta;
   const int32_t *subtree_end, *run_ptr, *runs, *ktile_qend;
+  const int32_t *dkv_units, *dkv_splits; float* dkv_ws;     // split-Q work units of the dK/dV sweep (NULL: one unit per key tile)
   int32_t Tq, Tk, q_offset, Hq, Hkv, group;
   int64_t q_st, q_sh, kv_st, kv_sh, o_st, o_sh, dq_st, dq_sh, dkv_st, dkv_sh;
   float scale; int32_t accumulate;
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
         for (int j = 0; j < 4; ++j) w[j] = (e)(O[db][4 * gq + j] * inv);
         *reinterpret_cast<v4*>(op + 32 * db + 8 * gq + 4 * h) = w;
       }
-    if (h == 0) p.lse_w[(int64_t)qrow * p.Hq + hq] = m + __builtin_amdgcn_logf(lsum);   // v_log_f32 = log2
+    if (h == 0) p.lse_w[(int64_t)hq * p.Tq + qrow] = m + __builtin_amdgcn_logf(lsum);   // v_log_f32 = log2
   }
 }
 
@@ -323,8 +325,8 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
   }
   dsum += __shfl_xor(dsum, 32);
   const float delta = dsum;
-  const float lse2 = p.lse_r[(int64_t)qrow_c * p.Hq + hq];
-  if (h == 0 && qrow < p.Tq) p.delta[(int64_t)qrow * p.Hq + hq] = delta;
+  const float lse2 = p.lse_r[(int64_t)hq * p.Tq + qrow_c];
+  if (h == 0 && qrow < p.Tq) p.delta[(int64_t)hq * p.Tq + qrow] = delta;
 
   TileIter it; it.runs = p.runs; it.diag_first_q = p.q_offset + q0;
   bool any = true;
@@ -349,11 +351,12 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
     for (int g = 0; g < 16; ++g) DQ[db][g] = 0.f;
   const float c = p.scale * LOG2E;
 
+  const float delta_s = delta * p.scale;
   if (any) {
-    int ck0 = it.k0;
+    int ck0 = it.k0; bool cmask = it.masked();
     DQ_LOAD(it.k0, it.kend) DQ_WRITE(0)
     bool has_next = it.advance();
-    int nk0 = it.k0;
+    int nk0 = it.k0; bool nmask = has_next ? it.masked() : false;
     if (has_next) DQ_LOAD(it.k0, it.kend)
     __syncthreads();
     int cur = 0;
@@ -377,19 +380,24 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
           X = T::mma(row_frag<v8>(Ks, 32 * kb + r, 2 * s + h), qf[s], X);
           DP = T::mma(row_frag<v8>(Vs, 32 * kb + r, 2 * s + h), dof[s], DP);
         }
-        // dS^T = P ∘ (dP − delta) · scale; always masked (exact zeros matter; 4 LDS reads per block)
+        // dS^T = P ∘ (dP·scale − delta·scale); the interval mask only on tiles of runs flagged partial
+        if (cmask) {
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int kl = 32 * kb + 8 * gq + 4 * h;
-          const int4 se4 = *reinterpret_cast<const int4*>(se_s + kl);
-          const int sev[4] = {se4.x, se4.y, se4.z, se4.w};
+          for (int gq = 0; gq < 4; ++gq) {
+            const int kl = 32 * kb + 8 * gq + 4 * h;
+            const int4 se4 = *reinterpret_cast<const int4*>(se_s + kl);
+            const int sev[4] = {se4.x, se4.y, se4.z, se4.w};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int g = 4 * gq + j;
-            const bool ok = (ck0 + kl + j <= qidx) && (qidx < sev[j]);
-            const float pv = ok ? fast_exp2(__builtin_fmaf(X[g], c, -lse2)) : 0.f;
-            X[g] = pv * (DP[g] - delta) * p.scale;
+            for (int j = 0; j < 4; ++j) {
+              const int g = 4 * gq + j;
+              const bool ok = (ck0 + kl + j <= qidx) && (qidx < sev[j]);
+              const float pv = ok ? fast_exp2(__builtin_fmaf(X[g], c, -lse2)) : 0.f;
+              X[g] = pv * __builtin_fmaf(DP[g], p.scale, -delta_s);
+            }
           }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) X[g] = fast_exp2(__builtin_fmaf(X[g], c, -lse2)) * __builtin_fmaf(DP[g], p.scale, -delta_s);
         }
         // dQ^T[d][q] += K^T · dS^T
 #pragma unroll
@@ -401,8 +409,8 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
       }
       __syncthreads();
       if (!has_next) break;
-      cur ^= 1; ck0 = nk0;
-      has_next = has_next2; nk0 = it.k0;
+      cur ^= 1; ck0 = nk0; cmask = nmask;
+      has_next = has_next2; nk0 = it.k0; nmask = has_next2 ? it.masked() : false;
     }
   }
 #undef DQ_LOAD
@@ -434,13 +442,26 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int bid = blockIdx.x;
-  const int kvh = bid % p.Hkv; const int kt = bid / p.Hkv;           // root-side (heaviest) key tiles come first in packed order
+  const int kvh = bid % p.Hkv; const int unit = bid / p.Hkv;
+  // a unit = (key tile, packed query range, slab): heavy key tiles (root-side: every query below them sees
+  // them) are cut into several units so that no workgroup carries a serial chain of hundreds of tiles
+  const int kt = p.dkv_units ? p.dkv_units[4 * unit] : unit;
+  const int slab = p.dkv_units ? p.dkv_units[4 * unit + 3] : -1;
   const int k0 = kt * DTA_KTILE;
   const int kidx = k0 + wave * 32 + r;
   const int kidx_c = kidx < p.Tk ? kidx : p.Tk - 1;
   const int q_hi = p.q_offset + p.Tq;
   int se_l = (kidx < p.Tk) ? (p.subtree_end ? p.subtree_end[kidx] : 0x7fffffff) : 0;
   se_l = se_l < q_hi ? se_l : q_hi;
+  // smallest subtree end over the workgroup's 128 keys: query tiles entirely below it (and below the
+  // key tile itself) need no mask at all
+  __shared__ int se_min_s[4];
+  { int mn = se_l;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
+    if (lane == 0) se_min_s[wave] = mn; }
+  __syncthreads();
+  const int se_min = min(min(se_min_s[0], se_min_s[1]), min(se_min_s[2], se_min_s[3]));
 
   const e* kp = reinterpret_cast<const e*>(p.k) + (int64_t)kidx_c * p.kv_st + (int64_t)kvh * p.kv_sh;
   const e* vp = reinterpret_cast<const e*>(p.v) + (int64_t)kidx_c * p.kv_st + (int64_t)kvh * p.kv_sh;
@@ -454,8 +475,12 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) { DK[db][g] = 0.f; DV[db][g] = 0.f; }
 
-  const int qbeg = k0 > p.q_offset ? k0 : p.q_offset;                // packed index of the first query that can see a key here
-  int qend = p.ktile_qend ? p.ktile_qend[kt] : q_hi; qend = qend < q_hi ? qend : q_hi;
+  int qbeg, qend;
+  if (p.dkv_units) { qbeg = p.dkv_units[4 * unit + 1]; qend = p.dkv_units[4 * unit + 2]; }
+  else {
+    qbeg = k0 > p.q_offset ? k0 : p.q_offset;                        // packed index of the first query that can see a key here
+    qend = p.ktile_qend ? p.ktile_qend[kt] : q_hi; qend = qend < q_hi ? qend : q_hi;
+  }
   const int ntile = qend > qbeg ? (qend - qbeg + 63) / 64 : 0;
   const int total = ntile * p.group;
   const float c = p.scale * LOG2E;
@@ -468,7 +493,7 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
     const e* db_ = reinterpret_cast<const e*>(p.dout) + (int64_t)hq_ * p.o_sh;                             \
     DTA_STAGE_LOAD(qreg, dreg, qb_, db_, p.q_st, p.o_st, row0_, p.Tq, NT, CPT)                             \
     if (tid < 64) { int qr_ = row0_ + tid; qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;                              \
-      lreg = p.lse_r[(int64_t)qr_ * p.Hq + hq_]; dlreg = p.delta[(int64_t)qr_ * p.Hq + hq_]; } }
+      lreg = p.lse_r[(int64_t)hq_ * p.Tq + qr_]; dlreg = p.delta[(int64_t)hq_ * p.Tq + qr_] * p.scale; } }
 #define KV_WRITE(B)                                                                                        \
   { char* base_ = smem + (B) * (2 * TILE_BYTES + 512);                                                     \
     DTA_STAGE_WRITE(qreg, dreg, base_, base_ + TILE_BYTES, NT, CPT)                                        \
@@ -488,39 +513,48 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
       const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * TILE_BYTES); const float* del_s = lse_s + 64;
       const int ti = idx % ntile;
       const int qi0 = qbeg + 64 * ti;                                   // packed index of image row 0
-      f32x16 S[2], DP[2];
+      const bool full = (qi0 >= k0 + DTA_KTILE - 1) && (qi0 + 63 < se_min);   // workgroup-uniform: no mask needed
+      // one 32-row query block at a time: S and dP stay at 32 live accumulators
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
+        f32x16 S, DP;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) { S[qb][g] = 0.f; DP[qb][g] = 0.f; }
+        for (int g = 0; g < 16; ++g) { S[g] = 0.f; DP[g] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-          S[qb] = T::mma(row_frag<v8>(Qs, 32 * qb + r, 2 * s + h), kf[s], S[qb]);
-          DP[qb] = T::mma(row_frag<v8>(Ds, 32 * qb + r, 2 * s + h), vf[s], DP[qb]);
+          S = T::mma(row_frag<v8>(Qs, 32 * qb + r, 2 * s + h), kf[s], S);
+          DP = T::mma(row_frag<v8>(Ds, 32 * qb + r, 2 * s + h), vf[s], DP);
         }
-      }
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
+        float lv[16], dv_[16];                                             // lse and delta*scale of this lane's 16 rows
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int ql = 32 * qb + 8 * gq + 4 * h;
           const float4 l4 = *reinterpret_cast<const float4*>(lse_s + ql);
           const float4 d4 = *reinterpret_cast<const float4*>(del_s + ql);
-          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}; const float dv_[4] = {d4.x, d4.y, d4.z, d4.w};
+          lv[4 * gq] = l4.x; lv[4 * gq + 1] = l4.y; lv[4 * gq + 2] = l4.z; lv[4 * gq + 3] = l4.w;
+          dv_[4 * gq] = d4.x; dv_[4 * gq + 1] = d4.y; dv_[4 * gq + 2] = d4.z; dv_[4 * gq + 3] = d4.w;
+        }
+        if (full) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int g = 4 * gq + j;
-            const int qi = qi0 + ql + j;
+          for (int g = 0; g < 16; ++g) {
+            const float pv = fast_exp2(__builtin_fmaf(S[g], c, -lv[g]));
+            S[g] = pv;
+            DP[g] = pv * __builtin_fmaf(DP[g], p.scale, -dv_[g]);
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            const int qi = qi0 + 32 * qb + 8 * (g >> 2) + 4 * h + (g & 3);
             const bool ok = (kidx <= qi) && (qi < se_l);
-            const float pv = ok ? fast_exp2(__builtin_fmaf(S[qb][g], c, -lv[j])) : 0.f;
-            S[qb][g] = pv;
-            DP[qb][g] = pv * (DP[qb][g] - dv_[j]) * p.scale;
+            const float pv = ok ? fast_exp2(__builtin_fmaf(S[g], c, -lv[g])) : 0.f;
+            S[g] = pv;
+            DP[g] = pv * __builtin_fmaf(DP[g], p.scale, -dv_[g]);
           }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const v8 pb = pack_half<DT>(S[qb], s2);
-          const v8 sb = pack_half<DT>(DP[qb], s2);
+          const v8 pb = pack_half<DT>(S, s2);
+          const v8 sb = pack_half<DT>(DP, s2);
 #pragma unroll
           for (int db = 0; db < 4; ++db) {
             DV[db] = T::mma(tr_frag<v8>(Ds, 32 * qb + 16 * s2, db, lane), pb, DV[db]);
@@ -534,7 +568,18 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
   }
 #undef KV_LOAD
 #undef KV_WRITE
-  if (kidx < p.Tk) {
+  if (slab >= 0) {
+    // partial sums of a split key tile: fp32 slab [2][128 keys][128 d], summed in unit order by the finalize kernel
+    float* ws = p.dkv_ws + ((int64_t)slab * p.Hkv + kvh) * (2 * DTA_KTILE * 128) + (int64_t)(wave * 32 + r) * 128;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = 32 * db + 8 * gq + 4 * h;
+        *reinterpret_cast<float4*>(ws + d) = make_float4(DK[db][4 * gq], DK[db][4 * gq + 1], DK[db][4 * gq + 2], DK[db][4 * gq + 3]);
+        *reinterpret_cast<float4*>(ws + DTA_KTILE * 128 + d) = make_float4(DV[db][4 * gq], DV[db][4 * gq + 1], DV[db][4 * gq + 2], DV[db][4 * gq + 3]);
+      }
+  } else if (kidx < p.Tk) {
     e* dkp = reinterpret_cast<e*>(p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
     e* dvp = reinterpret_cast<e*>(p.dv) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
 #pragma unroll
@@ -554,6 +599,29 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
         *reinterpret_cast<v4*>(dkp + d) = wk;
         *reinterpret_cast<v4*>(dvp + d) = wv;
       }
+  }
+}
+
+// Sums the fp32 slabs of every split key tile in a fixed order and writes dK/dV (bitwise reproducible).
+// dkv_splits[s] = {key tile, first slab, number of slabs, 0}.
+template <int DT>
+__global__ __launch_bounds__(256) void tree_attn_bwd_dkv_finalize_kernel(AttnParams p) {
+  using e = typename Ty<DT>::e;
+  const int kvh = blockIdx.x % p.Hkv, sp = blockIdx.x / p.Hkv;
+  const int kt = p.dkv_splits[4 * sp], first = p.dkv_splits[4 * sp + 1], n = p.dkv_splits[4 * sp + 2];
+  for (int i = threadIdx.x; i < 2 * DTA_KTILE * 32; i += 256) {          // float4 index inside a slab
+    const int which = i / (DTA_KTILE * 32), rem = i - which * DTA_KTILE * 32;
+    const int key = rem >> 5, d = (rem & 31) << 2;
+    const int kidx = kt * DTA_KTILE + key;
+    if (kidx >= p.Tk) continue;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < n; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(p.dkv_ws + ((int64_t)(first + j) * p.Hkv + kvh) * (2 * DTA_KTILE * 128) + (int64_t)i * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    e* out = reinterpret_cast<e*>(which ? p.dv : p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh + d;
+    if (p.accumulate) { acc.x += (float)out[0]; acc.y += (float)out[1]; acc.z += (float)out[2]; acc.w += (float)out[3]; }
+    out[0] = (e)acc.x; out[1] = (e)acc.y; out[2] = (e)acc.z; out[3] = (e)acc.w;
   }
 }
 
@@ -596,15 +664,19 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
                                     int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
                                     int64_t q_st, int64_t q_sh, int64_t kv_st, int64_t kv_sh, int64_t o_st, int64_t o_sh,
                                     int64_t dq_st, int64_t dq_sh, int64_t dkv_st, int64_t dkv_sh,
-                                    float scale, int32_t dtype, int32_t accumulate, int32_t which, void* stream) {
+                                    float scale, int32_t dtype, int32_t accumulate, int32_t which,
+                                    const int32_t* dkv_units, int32_t n_units, const int32_t* dkv_splits, int32_t n_splits, float* dkv_ws,
+                                    void* stream) {
   if (!q || !k || !v || !out || !dout || !lse || !delta || !dq || !dk || !dv || Tq <= 0 || Tk <= 0 || Hq <= 0 || Hkv <= 0 || q_offset < 0) return DTA_EINVAL;
   if ((runs == nullptr) != (run_ptr == nullptr)) return DTA_EINVAL;
+  if (dkv_units && (n_units <= 0 || n_splits < 0 || (n_splits > 0 && (!dkv_splits || !dkv_ws)))) return DTA_EINVAL;
   if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16)) return DTA_EUNSUPPORTED;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) ||
       (q_st | q_sh | kv_st | kv_sh | o_st | o_sh | dq_st | dq_sh | dkv_st | dkv_sh) % 8 != 0) return DTA_EALIGN;
   AttnParams p{};
   p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse_r = lse; p.delta = delta; p.dq = dq; p.dk = dk; p.dv = dv;
   p.subtree_end = subtree_end; p.run_ptr = run_ptr; p.runs = runs; p.ktile_qend = ktile_qend;
+  p.dkv_units = dkv_units; p.dkv_splits = dkv_splits; p.dkv_ws = dkv_ws;
   p.Tq = Tq; p.Tk = Tk; p.q_offset = q_offset; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
   p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.o_st = o_st; p.o_sh = o_sh;
   p.dq_st = dq_st; p.dq_sh = dq_sh; p.dkv_st = dkv_st; p.dkv_sh = dkv_sh; p.scale = scale; p.accumulate = accumulate;
@@ -613,14 +685,17 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();   // drop a stale error of an earlier, unrelated runtime call
   if ((which & 3) == 0) return DTA_EINVAL;
+  const int ndkv = dkv_units ? n_units : nkt;
   const bool pair = p.group % 2 == 0;
   const dim3 gq(pair ? nqt * Hq / 2 : nqt * Hq), bq(pair ? 512 : 256);
   if (dtype == DTA_BF16) {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 1>), gq, bq, 0, st, p); }
-    if (which & 2) hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_BF16>, dim3(nkt * Hkv), dim3(256), 0, st, p);
+    if (which & 2) { hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_BF16>, dim3(ndkv * Hkv), dim3(256), 0, st, p);
+                     if (dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_BF16>, dim3(n_splits * Hkv), dim3(256), 0, st, p); }
   } else {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 1>), gq, bq, 0, st, p); }
-    if (which & 2) hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_F16>, dim3(nkt * Hkv), dim3(256), 0, st, p);
+    if (which & 2) { hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_F16>, dim3(ndkv * Hkv), dim3(256), 0, st, p);
+                     if (dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_F16>, dim3(n_splits * Hkv), dim3(256), 0, st, p); }
   }
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
 }
@@ -645,5 +720,5 @@ extern "C" int dta_tree_attn_bwd(const void* q, const void* k, const void* v, co
                                  float scale, int32_t dtype, int32_t accumulate, void* stream) {
   return dta_tree_attn_bwd_ex(q, k, v, out, dout, lse, delta, dq, dk, dv, subtree_end, run_ptr, runs, ktile_qend,
                               Tq, Tk, q_offset, Hq, Hkv, head_dim, q_stride_t, 128, kv_stride_t, 128, o_stride_t, 128,
-                              dq_stride_t, 128, dkv_stride_t, 128, scale, dtype, accumulate, 3, stream);
+                              dq_stride_t, 128, dkv_stride_t, 128, scale, dtype, accumulate, 3, nullptr, 0, nullptr, 0, nullptr, stream);
 }

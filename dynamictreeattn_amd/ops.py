@@ -51,7 +51,9 @@ class TreeAttnMeta:
     runs: Optional[torch.Tensor]             # int32 [nruns,4]
     ktile_qend: Optional[torch.Tensor]       # int32 [nkt]
     q_offset: int = 0
-    pairs: int = 0                           # number of visible (query,key) pairs (for FLOP accounting)
+    dkv_units: Optional[torch.Tensor] = None     # int32 [n,4] balanced work units of the dK/dV sweep (packing.plan_dkv_units)
+    dkv_splits: Optional[torch.Tensor] = None    # int32 [m,4]
+    n_slabs: int = 0
 
 
 def ktile_qend_from(subtree_end: torch.Tensor, tile: int = packing.KTILE) -> torch.Tensor:
@@ -75,7 +77,7 @@ def attn_fwd_raw(q, k, v, meta: TreeAttnMeta, scale: float):
     if k.stride() != v.stride():
         v = v.contiguous(); k = k.contiguous()
     out = torch.empty((Tq, Hq, D), dtype=q.dtype, device=q.device)
-    lse = torch.empty((Tq, Hq), dtype=torch.float32, device=q.device)
+    lse = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device)          # head-major: rows of one head are contiguous
     (qs, qh), (ks, kh), (os_, oh) = _strides(q), _strides(k), _strides(out)
     tm = KernelTimer.active
     if tm is not None:
@@ -96,13 +98,19 @@ def attn_bwd_raw(q, k, v, out, dout, lse, meta: TreeAttnMeta, scale: float, dk=N
     dq = torch.empty((Tq, Hq, D), dtype=q.dtype, device=q.device)
     if dk is None:
         dk = torch.empty((Tk, Hkv, D), dtype=q.dtype, device=q.device); dv = torch.empty_like(dk)
-    delta = torch.empty((Tq, Hq), dtype=torch.float32, device=q.device)
+    delta = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device)
     (qs, qh), (ks, kh), (os_, oh), (dqs, dqh), (dks, dkh) = _strides(q), _strides(k), _strides(out), _strides(dq), _strides(dk)
+    units, splits = meta.dkv_units, meta.dkv_splits
+    n_units = units.shape[0] if units is not None else 0
+    n_splits = splits.shape[0] if splits is not None else 0
+    ws = torch.empty((meta.n_slabs, Hkv, 2, packing.KTILE, D), dtype=torch.float32, device=q.device) if (units is not None and meta.n_slabs) else None
+
     def launch(which):
         return lib().dta_tree_attn_bwd_ex(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                                           ptr(meta.subtree_end), ptr(meta.run_ptr), ptr(meta.runs), ptr(meta.ktile_qend),
                                           Tq, Tk, meta.q_offset, Hq, Hkv, D, qs, qh, ks, kh, os_, oh, dqs, dqh, dks, dkh,
-                                          float(scale), _DT[q.dtype], 1 if accumulate else 0, which, _stream())
+                                          float(scale), _DT[q.dtype], 1 if accumulate else 0, which,
+                                          ptr(units), n_units, ptr(splits) if n_splits else None, n_splits, ptr(ws), _stream())
     tm = KernelTimer.active
     if tm is None:
         check(launch(3), "dta_tree_attn_bwd")
@@ -141,11 +149,23 @@ def stack_meta(start: int) -> TreeAttnMeta:
     return TreeAttnMeta(T=0, subtree_end=None, run_ptr=None, runs=None, ktile_qend=None, q_offset=start)
 
 
-def meta_from_plan(plan: packing.SegmentPlan, subtree_end: torch.Tensor, device) -> TreeAttnMeta:
+def attach_dkv_units(meta: TreeAttnMeta, Hkv: int) -> TreeAttnMeta:
+    """Plans the balanced dK/dV work units from ktile_qend (one small D2H read) and uploads them."""
+    kq = meta.ktile_qend.cpu().numpy()
+    units, splits, n_slabs = packing.plan_dkv_units(kq, meta.T, meta.T, meta.q_offset, Hkv)
+    dev = meta.ktile_qend.device
+    meta.dkv_units = torch.from_numpy(units).to(dev).contiguous()
+    meta.dkv_splits = torch.from_numpy(splits).to(dev).contiguous() if splits.shape[0] else None
+    meta.n_slabs = n_slabs
+    return meta
+
+
+def meta_from_plan(plan: packing.SegmentPlan, subtree_end: torch.Tensor, device, Hkv: int = 8) -> TreeAttnMeta:
     rp, runs = packing.plan_qtile_runs(plan)
-    return TreeAttnMeta(T=plan.T, subtree_end=subtree_end,
+    meta = TreeAttnMeta(T=plan.T, subtree_end=subtree_end,
                         run_ptr=torch.from_numpy(rp).to(device), runs=torch.from_numpy(runs).to(device).contiguous(),
                         ktile_qend=ktile_qend_from(subtree_end))
+    return attach_dkv_units(meta, Hkv)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -149,3 +149,36 @@ def plan_qtile_runs(plan: SegmentPlan, tile: int = QTILE):
             out.append((cb, ce, 1, 0))
         run_ptr.append(len(out))
     return np.asarray(run_ptr, np.int32), np.asarray(out, np.int32).reshape(-1, 4)
+
+
+def plan_dkv_units(ktile_qend: np.ndarray, Tk: int, Tq: int, q_offset: int = 0, Hkv: int = 8, tile: int = KTILE,
+                   waves_per_cu: int = 6, n_cu: int = 256, min_tiles: int = 8):
+    """Balanced work units of the dK/dV sweep.  Key tile j must visit the 64-row query tiles of
+    [max(key0, q_offset), ktile_qend[j]); root-side key tiles are seen by every query below them, so
+    their sweep is hundreds of tiles long while leaf-side tiles need a handful.  Tiles longer than the
+    cap are cut into equal units; units of a cut tile write fp32 slabs that a finalize launch sums in
+    unit order.  Returns (units int32 [n,4] = {key tile, q_begin, q_end, slab|-1} heaviest first,
+    splits int32 [m,4] = {key tile, first slab, n slabs, 0}, n_slabs)."""
+    nkt = ktile_qend.shape[0]
+    k0 = np.arange(nkt, dtype=np.int64) * tile
+    qbeg = np.maximum(k0, q_offset)
+    qend = np.minimum(ktile_qend.astype(np.int64), q_offset + Tq)
+    ntile = np.maximum(0, -(-(qend - qbeg) // 64))
+    total = int(ntile.sum())
+    target = max(1, (waves_per_cu * n_cu) // max(Hkv, 1))
+    cap = max(min_tiles, -(-total // target))
+    nsplit = np.maximum(1, -(-ntile // cap))
+    per = -(-ntile // nsplit)                                    # query tiles per unit
+    kt_of = np.repeat(np.arange(nkt, dtype=np.int64), nsplit)
+    first_unit = np.cumsum(nsplit) - nsplit
+    j = np.arange(kt_of.shape[0], dtype=np.int64) - first_unit[kt_of]
+    ub = qbeg[kt_of] + j * per[kt_of] * 64
+    ue = np.minimum(qend[kt_of], ub + per[kt_of] * 64)
+    is_split = nsplit[kt_of] > 1
+    slab = np.where(is_split, np.cumsum(is_split) - 1, -1)
+    units = np.stack([kt_of, ub, np.maximum(ue, ub), slab], axis=1)
+    order = np.argsort(-(units[:, 2] - units[:, 1]), kind="stable")
+    split_kt = np.flatnonzero(nsplit > 1)
+    first_slab = (np.cumsum(np.where(nsplit > 1, nsplit, 0)) - np.where(nsplit > 1, nsplit, 0))[split_kt]
+    splits = np.stack([split_kt, first_slab, nsplit[split_kt], np.zeros_like(split_kt)], axis=1) if split_kt.size else np.zeros((0, 4), np.int64)
+    return units[order].astype(np.int32), splits.astype(np.int32), int(is_split.sum())

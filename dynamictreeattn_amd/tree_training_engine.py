@@ -83,7 +83,7 @@ def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tenso
 class _PackedTrie:
     """Device-resident packed form of a TokenTrie (in its current leaf order)."""
 
-    def __init__(self, trie, device):
+    def __init__(self, trie, device, n_kv_heads: int = 8):
         self.plan = plan = packing.plan_segments(trie.lens, trie.lcp_lens)
         M, T = plan.M, plan.T
         run_ptr, runs = packing.plan_qtile_runs(plan)
@@ -105,6 +105,7 @@ class _PackedTrie:
         self._expand(trie._dev.tokens, leaf_off_d, seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, M, T)
         self.meta = ops.TreeAttnMeta(T=T, subtree_end=self.subtree_end, run_ptr=run_ptr_d, runs=runs_d.view(-1, 4),
                                      ktile_qend=ops.ktile_qend_from(self.subtree_end))
+        ops.attach_dkv_units(self.meta, n_kv_heads)
         first = plan.seg_off[:-1].astype(np.int64)
         nonempty = np.diff(plan.seg_off) > 0
         par = plan.parent_of_seg.astype(np.int64)
@@ -135,6 +136,7 @@ class TreeTrainingEngine:
         self.max_seq_len = max_seq_len
         self.forward_only = forward_only
         self.n_layers = model_config.num_hidden_layers
+        self.n_kv_heads = getattr(model_config, "num_key_value_heads", 8)
         self.cur_len = 0                      # the packed engine is stateless between calls (reference: tte:550, 614-615)
         self.forkpos_list: List[int] = []
         self.returns: List[Optional[torch.Tensor]] = []
@@ -147,7 +149,7 @@ class TreeTrainingEngine:
         longest = max(token_trie.lens) if token_trie.lens else 0
         assert longest <= self.max_seq_len, (                                   # tte:162-164, 289-291
             f"Exceeds max_seq_len: cur_len=0, new_tokens={longest}, max={self.max_seq_len}")
-        packed = _PackedTrie(token_trie, self.device)
+        packed = _PackedTrie(token_trie, self.device, self.n_kv_heads)
         self.last_packed = packed
         return packed
 

@@ -86,7 +86,7 @@ int dta_preorder_meta(const int64_t* tokens, const int64_t* leaf_tok_off,
  * Query tiles are DTA_QTILE rows.  Tile j visits the key runs runs[run_ptr[j] .. run_ptr[j+1]),
  * each run = 4 int32 {key_begin, key_end, needs_mask, 0}; runs == NULL: one run [0, last row + 1).
  * A run with needs_mask == 0 promises that every key in it is visible to every row of the tile.
- * lse: [Tq, Hq] float, log2-domain log-sum-exp of the scaled scores (natural lse = lse * ln 2).
+ * lse: [Hq, Tq] float (head-major), log2-domain log-sum-exp of the scaled scores (natural lse = lse * ln 2).
  * Replaces the attention the reference reaches through the model call,
  * tree_training_engine.py:182-186, 248-252, 351-353 (third-party attention backend).  */
 int dta_tree_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
@@ -108,7 +108,7 @@ int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v, void* out,
  * [max(key0, q_offset), ktile_qend[tile]) and over the Hq/Hkv query heads of the group — no
  * cross-workgroup reduction, no atomics, bitwise reproducible.  ktile_qend[j] = max subtree_end
  * over the tile's keys (NULL: q_offset + Tq).  `accumulate` != 0 adds into dk/dv (the grad-KV
- * stack of tree_training_engine.py:447-451) instead of overwriting.  delta: [Tq, Hq] float workspace.
+ * stack of tree_training_engine.py:447-451) instead of overwriting.  delta: [Hq, Tq] float workspace.
  * Replaces torch.autograd.backward through the attention backend, tree_training_engine.py:440.  */
 int dta_tree_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                       const float* lse, float* delta, void* dq, void* dk, void* dv,
@@ -128,7 +128,13 @@ int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v, const void
                          int64_t o_stride_t, int64_t o_stride_h, int64_t dq_stride_t, int64_t dq_stride_h,
                          int64_t dkv_stride_t, int64_t dkv_stride_h,
                          float scale, int32_t dtype, int32_t accumulate,
-                         int32_t which /* bit0: delta+dq launch, bit1: dk/dv launch (needs delta) */, void* stream);
+                         int32_t which /* bit0: delta+dq launch, bit1: dk/dv launch (needs delta) */,
+                         /* optional split of the dK/dV sweep into balanced work units (NULL: one per key tile):
+                          * dkv_units[u] = {key tile, q_begin, q_end (packed), slab or -1}; units of a split key tile
+                          * write fp32 slabs [2][DTA_KTILE][128] into dkv_ws (slab-major, then kv head) which a finalize
+                          * launch sums in order: dkv_splits[s] = {key tile, first slab, n slabs, 0}. */
+                         const int32_t* dkv_units, int32_t n_units, const int32_t* dkv_splits, int32_t n_splits, float* dkv_ws,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Log-prob / entropy over vocabulary rows (HBM-bound).  logits: [R, V] bf16/f16 with row_stride

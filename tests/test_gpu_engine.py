@@ -92,3 +92,36 @@ def test_f16_and_layer_checkpointing_agree():
     l2 = e.backward(m, t, mo.default_loss, 64)
     assert abs(l1 - l2) < 1e-3 * abs(l1)
     assert max(mo.grad_ratio(g1[n], p.grad.float()) for n, p in m.named_parameters()) < 5e-3
+
+
+def test_qwen3_0p6b_config1_tree_vs_dense_within_recorded_bound():
+    """BASELINE config 1 at full model size (Qwen3-0.6B dims, 310 tensors, random init seed 0, bf16):
+    the exp/compare_grads.py protocol behind grad/Qwen3-0.6B-TB-vs-DB-bf16.txt — per-parameter
+    |Δg|/|g| of tree-backward vs dense-backward — plus the reference's own fp32 loss / gradient norms
+    for the same seeded weights and batch (tests/golden/qwen3_0p6b_config1.json)."""
+    import json
+    cfg = synth.QWEN3_0P6B
+    w = mo.init_weights(cfg, seed=0)
+    m = Qwen3TreeLM.from_named(cfg, w, DEV, torch.bfloat16)
+    del w
+    seqs = synth.as_tensors(synth.config1(0, cfg["vocab_size"]))
+    att = lambda: [{"w_logprobs": -1.0, "w_entropy": 0.1} for _ in seqs]
+    t = TokenTrie(seqs, att()); t.backward_permute()
+    st = t.get_stats("backward", 2048)
+    assert (st["n_tokens"], st["n_tree_tokens"], st["sum_depth"]) == (2048, 1280, 425344)          # SURVEY §8d
+    lt = TreeTrainingEngine(m.config, DEV, torch.bfloat16, 512).backward(m, t, mo.default_loss, 2048)
+    gt = {n: p.grad.float().clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    ld = dense.backward(m, seqs, att(), mo.default_loss)
+    ratios = {n: mo.grad_ratio(p.grad.float(), gt[n]) for n, p in m.named_parameters()}
+    assert len(ratios) == 310
+    worst = max(ratios.items(), key=lambda kv: kv[1])
+    assert worst[1] <= REF_BF16_BOUND, worst
+    assert float(np.median(list(ratios.values()))) <= 2.55e-2
+    assert abs(lt - ld) < 2e-3 * abs(ld)
+    path = os.path.join(GOLD, "qwen3_0p6b_config1.json")
+    if os.path.exists(path):
+        ref = json.load(open(path))
+        assert abs(ld - ref["loss_dense"]) < 5e-3 * abs(ref["loss_dense"]) and abs(lt - ref["loss_tree"]) < 5e-3 * abs(ref["loss_tree"])
+        for n, p in m.named_parameters():
+            assert abs(float(p.grad.float().norm()) - ref["norm_dense"][n]) <= 0.08 * ref["norm_dense"][n] + 1e-4, n
