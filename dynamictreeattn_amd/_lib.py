@@ -17,8 +17,8 @@ _PROTOS = {
     "dta_preorder_meta": ([_vp] * 8 + [_i32, _i32] + [_vp] * 4 + [_vp], C.c_int),
     "dta_tree_attn_fwd": ([_vp] * 8 + [_i32] * 6 + [_i64] * 3 + [_f32, _i32, _vp], C.c_int),
     "dta_tree_attn_bwd": ([_vp] * 14 + [_i32] * 6 + [_i64] * 5 + [_f32, _i32, _i32, _vp], C.c_int),
-    "dta_tree_attn_fwd_ex": ([_vp] * 8 + [_i32] * 6 + [_i64] * 6 + [_f32, _i32, _vp], C.c_int),
-    "dta_tree_attn_bwd_ex": ([_vp] * 14 + [_i32] * 6 + [_i64] * 10 + [_f32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp], C.c_int),
+    "dta_tree_attn_fwd_ex": ([_vp] * 8 + [_i32] * 6 + [_i64] * 8 + [_f32, _i32, _vp], C.c_int),
+    "dta_tree_attn_bwd_ex": ([_vp] * 14 + [_i32] * 6 + [_i64] * 12 + [_f32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp], C.c_int),
     "dta_logprob_entropy_fwd": ([_vp] * 5 + [_i32, _i32, _i64, _f32, _i32, _vp], C.c_int),
     "dta_logprob_entropy_bwd": ([_vp] * 7 + [_i32, _i32, _i64, _f32, _i32, _vp], C.c_int),
     "dta_rmsnorm_fwd": ([_vp] * 4 + [_i32, _i32, _f32, _i32, _vp], C.c_int),
@@ -27,8 +27,8 @@ _PROTOS = {
     "dta_qk_norm_rope_fwd": ([_vp] * 5 + [_i32, _i32, _i32, _i64, _f32, _i32, _vp], C.c_int),
     "dta_qk_norm_rope_bwd_blocks": ([_i64], C.c_int),
     "dta_qk_norm_rope_bwd": ([_vp] * 7 + [_i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
-    "dta_swiglu_fwd": ([_vp] * 3 + [_i64, _i32, _vp], C.c_int),
-    "dta_swiglu_bwd": ([_vp] * 5 + [_i64, _i32, _vp], C.c_int),
+    "dta_swiglu_fwd": ([_vp] * 3 + [_i64, _i32, _i64, _i32, _vp], C.c_int),
+    "dta_swiglu_bwd": ([_vp] * 5 + [_i64, _i32, _i64, _i64, _i32, _vp], C.c_int),
 }
 EXPORTS = tuple(_PROTOS)
 _ERR = {-1: "DTA_EINVAL", -2: "DTA_EUNSUPPORTED", -3: "DTA_EALIGN", -4: "DTA_ELAUNCH"}

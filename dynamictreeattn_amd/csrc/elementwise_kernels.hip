@@ -228,11 +228,16 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const void* __res
 }
 
 // ---------------------------------------------------------------------------------------------
+// SwiGLU on rows of C columns; gate/up (and their gradients) may live side by side in one fused
+// [rows, 2C] GEMM output: `ld` = elements between consecutive rows of g/u (dg/du).
 template <int DT>
-__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const void* __restrict__ g_, const void* __restrict__ u_, void* __restrict__ y_, int64_t n8) {
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const void* __restrict__ g_, const void* __restrict__ u_, void* __restrict__ y_,
+                                                         int64_t n8, int c8, int64_t ld) {
   using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-    const v8 g = reinterpret_cast<const v8*>(g_)[i]; const v8 u = reinterpret_cast<const v8*>(u_)[i];
+    const int64_t row = i / c8; const int col = (int)(i - row * c8) * 8;
+    const v8 g = *reinterpret_cast<const v8*>(reinterpret_cast<const e*>(g_) + row * ld + col);
+    const v8 u = *reinterpret_cast<const v8*>(reinterpret_cast<const e*>(u_) + row * ld + col);
     v8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const float x = (float)g[j]; const e s = (e)(x / (1.f + __expf(-x))); o[j] = (e)((float)s * (float)u[j]); }
@@ -242,10 +247,13 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const void* __restrict_
 
 template <int DT>
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const void* __restrict__ g_, const void* __restrict__ u_, const void* __restrict__ dy_,
-                                                         void* __restrict__ dg_, void* __restrict__ du_, int64_t n8) {
+                                                         void* __restrict__ dg_, void* __restrict__ du_, int64_t n8, int c8, int64_t ld, int64_t ldg) {
   using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-    const v8 g = reinterpret_cast<const v8*>(g_)[i]; const v8 u = reinterpret_cast<const v8*>(u_)[i]; const v8 dy = reinterpret_cast<const v8*>(dy_)[i];
+    const int64_t row = i / c8; const int col = (int)(i - row * c8) * 8;
+    const v8 g = *reinterpret_cast<const v8*>(reinterpret_cast<const e*>(g_) + row * ld + col);
+    const v8 u = *reinterpret_cast<const v8*>(reinterpret_cast<const e*>(u_) + row * ld + col);
+    const v8 dy = reinterpret_cast<const v8*>(dy_)[i];
     v8 dg, du;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -253,7 +261,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const void* __restrict_
       du[j] = (e)(d * x * sg);
       dg[j] = (e)(d * (float)u[j] * sg * (1.f + x * (1.f - sg)));
     }
-    reinterpret_cast<v8*>(dg_)[i] = dg; reinterpret_cast<v8*>(du_)[i] = du;
+    *reinterpret_cast<v8*>(reinterpret_cast<e*>(dg_) + row * ldg + col) = dg;
+    *reinterpret_cast<v8*>(reinterpret_cast<e*>(du_) + row * ldg + col) = du;
   }
 }
 
@@ -306,16 +315,19 @@ extern "C" int dta_qk_norm_rope_bwd(const void* x, const void* w, const float* c
   DTA_DISPATCH(qk_norm_rope_bwd_kernel, row_blocks(n, 16, 1024), x, w, cos_sin, dy, rstd, dx, dw_partial, n, NH, x_stride_t, dy_stride_t, dy_stride_h);
 }
 
-extern "C" int dta_swiglu_fwd(const void* gate, const void* up, void* y, int64_t n, int32_t dtype, void* stream) {
-  if (!gate || !up || !y || n <= 0) return DTA_EINVAL;
-  if ((dtype != DTA_BF16 && dtype != DTA_F16) || n % 8) return DTA_EUNSUPPORTED;
+extern "C" int dta_swiglu_fwd(const void* gate, const void* up, void* y, int64_t rows, int32_t cols, int64_t ld, int32_t dtype, void* stream) {
+  if (!gate || !up || !y || rows <= 0 || cols <= 0 || ld < cols) return DTA_EINVAL;
+  if ((dtype != DTA_BF16 && dtype != DTA_F16) || cols % 8 || ld % 8) return DTA_EUNSUPPORTED;
   if (!al16(gate) || !al16(up) || !al16(y)) return DTA_EALIGN;
-  DTA_DISPATCH(swiglu_fwd_kernel, row_blocks(n / 8, 256, 4096), gate, up, y, n / 8);
+  const int64_t n8 = rows * (cols / 8);
+  DTA_DISPATCH(swiglu_fwd_kernel, row_blocks(n8, 256, 4096), gate, up, y, n8, cols / 8, ld);
 }
 
-extern "C" int dta_swiglu_bwd(const void* gate, const void* up, const void* dy, void* dgate, void* dup, int64_t n, int32_t dtype, void* stream) {
-  if (!gate || !up || !dy || !dgate || !dup || n <= 0) return DTA_EINVAL;
-  if ((dtype != DTA_BF16 && dtype != DTA_F16) || n % 8) return DTA_EUNSUPPORTED;
+extern "C" int dta_swiglu_bwd(const void* gate, const void* up, const void* dy, void* dgate, void* dup,
+                              int64_t rows, int32_t cols, int64_t ld, int64_t ld_grad, int32_t dtype, void* stream) {
+  if (!gate || !up || !dy || !dgate || !dup || rows <= 0 || cols <= 0 || ld < cols || ld_grad < cols) return DTA_EINVAL;
+  if ((dtype != DTA_BF16 && dtype != DTA_F16) || cols % 8 || ld % 8 || ld_grad % 8) return DTA_EUNSUPPORTED;
   if (!al16(gate) || !al16(up) || !al16(dy) || !al16(dgate) || !al16(dup)) return DTA_EALIGN;
-  DTA_DISPATCH(swiglu_bwd_kernel, row_blocks(n / 8, 256, 4096), gate, up, dy, dgate, dup, n / 8);
+  const int64_t n8 = rows * (cols / 8);
+  DTA_DISPATCH(swiglu_bwd_kernel, row_blocks(n8, 256, 4096), gate, up, dy, dgate, dup, n8, cols / 8, ld, ld_grad);
 }

@@ -49,7 +49,7 @@ struct AttnParams {
   const int32_t *subtree_end, *run_ptr, *runs, *ktile_qend;
   const int32_t *dkv_units, *dkv_splits; float* dkv_ws;     // split-Q work units of the dK/dV sweep (NULL: one unit per key tile)
   int32_t Tq, Tk, q_offset, Hq, Hkv, group;
-  int64_t q_st, q_sh, kv_st, kv_sh, o_st, o_sh, dq_st, dq_sh, dkv_st, dkv_sh;
+  int64_t q_st, q_sh, kv_st, kv_sh, v_st, v_sh, o_st, o_sh, dq_st, dq_sh, dkv_st, dkv_sh;
   float scale; int32_t accumulate;
 };
 
@@ -176,10 +176,10 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
   for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const v8*>(qp + 16 * s + 8 * h);
 
   const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
-  const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.kv_sh;
+  const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.v_sh;
   u32x4 kreg[CPT], vreg[CPT]; int sereg = 0;
 #define FWD_LOAD(K0, KEND)                                                                                 \
-  { DTA_STAGE_LOAD(kreg, vreg, kbase, vbase, p.kv_st, p.kv_st, (K0), p.Tk, NT, CPT)                        \
+  { DTA_STAGE_LOAD(kreg, vreg, kbase, vbase, p.kv_st, p.v_st, (K0), p.Tk, NT, CPT)                        \
     if (tid < 64) { const int ki_ = (K0) + tid; sereg = (ki_ < (KEND)) ? (p.subtree_end ? p.subtree_end[ki_] : 0x7fffffff) : 0; } }
 #define FWD_WRITE(B)                                                                                       \
   { char* base_ = smem + (B) * (2 * TILE_BYTES + SE_BYTES);                                                \
@@ -334,10 +334,10 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
   else { it.ri = 0; it.re = 1; it.k0 = 0; it.flag = 1; int last = p.q_offset + (q0 + DTA_QTILE < p.Tq ? q0 + DTA_QTILE : p.Tq); it.kend = last < p.Tk ? last : p.Tk; any = it.kend > 0; }
 
   const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
-  const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.kv_sh;
+  const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.v_sh;
   u32x4 kreg[CPT], vreg[CPT]; int sereg = 0;
 #define DQ_LOAD(K0, KEND)                                                                                  \
-  { DTA_STAGE_LOAD(kreg, vreg, kbase, vbase, p.kv_st, p.kv_st, (K0), p.Tk, NT, CPT)                        \
+  { DTA_STAGE_LOAD(kreg, vreg, kbase, vbase, p.kv_st, p.v_st, (K0), p.Tk, NT, CPT)                        \
     if (tid < 64) { const int ki_ = (K0) + tid; sereg = (ki_ < (KEND)) ? (p.subtree_end ? p.subtree_end[ki_] : 0x7fffffff) : 0; } }
 #define DQ_WRITE(B)                                                                                        \
   { char* base_ = smem + (B) * (2 * TILE_BYTES + SE_BYTES);                                                \
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
   const int se_min = min(min(se_min_s[0], se_min_s[1]), min(se_min_s[2], se_min_s[3]));
 
   const e* kp = reinterpret_cast<const e*>(p.k) + (int64_t)kidx_c * p.kv_st + (int64_t)kvh * p.kv_sh;
-  const e* vp = reinterpret_cast<const e*>(p.v) + (int64_t)kidx_c * p.kv_st + (int64_t)kvh * p.kv_sh;
+  const e* vp = reinterpret_cast<const e*>(p.v) + (int64_t)kidx_c * p.v_st + (int64_t)kvh * p.v_sh;
   v8 kf[8], vf[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) { kf[s] = *reinterpret_cast<const v8*>(kp + 16 * s + 8 * h); vf[s] = *reinterpret_cast<const v8*>(vp + 16 * s + 8 * h); }
@@ -632,16 +632,16 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse,
                                     const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
                                     int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
-                                    int64_t q_st, int64_t q_sh, int64_t kv_st, int64_t kv_sh, int64_t o_st, int64_t o_sh,
+                                    int64_t q_st, int64_t q_sh, int64_t kv_st, int64_t kv_sh, int64_t v_st, int64_t v_sh, int64_t o_st, int64_t o_sh,
                                     float scale, int32_t dtype, void* stream) {
   if (!q || !k || !v || !out || !lse || Tq <= 0 || Tk <= 0 || Hq <= 0 || Hkv <= 0 || q_offset < 0) return DTA_EINVAL;
   if ((runs == nullptr) != (run_ptr == nullptr)) return DTA_EINVAL;
   if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16)) return DTA_EUNSUPPORTED;
-  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || (q_st | q_sh | kv_st | kv_sh | o_st | o_sh) % 8 != 0) return DTA_EALIGN;
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || (q_st | q_sh | kv_st | kv_sh | v_st | v_sh | o_st | o_sh) % 8 != 0) return DTA_EALIGN;
   AttnParams p{};
   p.q = q; p.k = k; p.v = v; p.out = out; p.lse_w = lse; p.subtree_end = subtree_end; p.run_ptr = run_ptr; p.runs = runs;
   p.Tq = Tq; p.Tk = Tk; p.q_offset = q_offset; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
-  p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.o_st = o_st; p.o_sh = o_sh; p.scale = scale;
+  p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.v_st = v_st; p.v_sh = v_sh; p.o_st = o_st; p.o_sh = o_sh; p.scale = scale;
   const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();   // drop a stale error of an earlier, unrelated runtime call
@@ -662,7 +662,7 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
                                     const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
                                     const int32_t* ktile_qend,
                                     int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
-                                    int64_t q_st, int64_t q_sh, int64_t kv_st, int64_t kv_sh, int64_t o_st, int64_t o_sh,
+                                    int64_t q_st, int64_t q_sh, int64_t kv_st, int64_t kv_sh, int64_t v_st, int64_t v_sh, int64_t o_st, int64_t o_sh,
                                     int64_t dq_st, int64_t dq_sh, int64_t dkv_st, int64_t dkv_sh,
                                     float scale, int32_t dtype, int32_t accumulate, int32_t which,
                                     const int32_t* dkv_units, int32_t n_units, const int32_t* dkv_splits, int32_t n_splits, float* dkv_ws,
@@ -672,13 +672,13 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   if (dkv_units && (n_units <= 0 || n_splits < 0 || (n_splits > 0 && (!dkv_splits || !dkv_ws)))) return DTA_EINVAL;
   if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16)) return DTA_EUNSUPPORTED;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) ||
-      (q_st | q_sh | kv_st | kv_sh | o_st | o_sh | dq_st | dq_sh | dkv_st | dkv_sh) % 8 != 0) return DTA_EALIGN;
+      (q_st | q_sh | kv_st | kv_sh | v_st | v_sh | o_st | o_sh | dq_st | dq_sh | dkv_st | dkv_sh) % 8 != 0) return DTA_EALIGN;
   AttnParams p{};
   p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse_r = lse; p.delta = delta; p.dq = dq; p.dk = dk; p.dv = dv;
   p.subtree_end = subtree_end; p.run_ptr = run_ptr; p.runs = runs; p.ktile_qend = ktile_qend;
   p.dkv_units = dkv_units; p.dkv_splits = dkv_splits; p.dkv_ws = dkv_ws;
   p.Tq = Tq; p.Tk = Tk; p.q_offset = q_offset; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
-  p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.o_st = o_st; p.o_sh = o_sh;
+  p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.v_st = v_st; p.v_sh = v_sh; p.o_st = o_st; p.o_sh = o_sh;
   p.dq_st = dq_st; p.dq_sh = dq_sh; p.dkv_st = dkv_st; p.dkv_sh = dkv_sh; p.scale = scale; p.accumulate = accumulate;
   const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
   const int nkt = (Tk + DTA_KTILE - 1) / DTA_KTILE;
@@ -707,7 +707,7 @@ extern "C" int dta_tree_attn_fwd(const void* q, const void* k, const void* v, vo
                                  int64_t q_stride_t, int64_t kv_stride_t, int64_t o_stride_t,
                                  float scale, int32_t dtype, void* stream) {
   return dta_tree_attn_fwd_ex(q, k, v, out, lse, subtree_end, run_ptr, runs, Tq, Tk, q_offset, Hq, Hkv, head_dim,
-                              q_stride_t, 128, kv_stride_t, 128, o_stride_t, 128, scale, dtype, stream);
+                              q_stride_t, 128, kv_stride_t, 128, kv_stride_t, 128, o_stride_t, 128, scale, dtype, stream);
 }
 
 extern "C" int dta_tree_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
@@ -719,6 +719,6 @@ extern "C" int dta_tree_attn_bwd(const void* q, const void* k, const void* v, co
                                  int64_t dq_stride_t, int64_t dkv_stride_t,
                                  float scale, int32_t dtype, int32_t accumulate, void* stream) {
   return dta_tree_attn_bwd_ex(q, k, v, out, dout, lse, delta, dq, dk, dv, subtree_end, run_ptr, runs, ktile_qend,
-                              Tq, Tk, q_offset, Hq, Hkv, head_dim, q_stride_t, 128, kv_stride_t, 128, o_stride_t, 128,
+                              Tq, Tk, q_offset, Hq, Hkv, head_dim, q_stride_t, 128, kv_stride_t, 128, kv_stride_t, 128, o_stride_t, 128,
                               dq_stride_t, 128, dkv_stride_t, 128, scale, dtype, accumulate, 3, nullptr, 0, nullptr, 0, nullptr, stream);
 }

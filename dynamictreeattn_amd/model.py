@@ -22,6 +22,8 @@ import torch.nn.functional as F
 
 from . import ops
 
+FUSE_PROJECTIONS = __import__("os").environ.get("DTA_FUSE_PROJ", "1") != "0"      # diagnostic A/B switch
+
 
 class _Norm(nn.Module):
     def __init__(self, n):
@@ -115,9 +117,17 @@ def _layer_forward(layer, x, cos_sin, meta, Hq, Hkv, D, eps):
     T = x.shape[0]
     a = layer.self_attn
     h = ops.rms_norm(x, layer.input_layernorm.weight, eps)
-    q = F.linear(h, a.q_proj.weight, getattr(a.q_proj, "bias", None)).view(T, Hq, D)
-    k = F.linear(h, a.k_proj.weight, getattr(a.k_proj, "bias", None)).view(T, Hkv, D)
-    v = F.linear(h, a.v_proj.weight, getattr(a.v_proj, "bias", None)).view(T, Hkv, D)
+    bq, bk, bv = (getattr(m_, "bias", None) for m_ in (a.q_proj, a.k_proj, a.v_proj))
+    if FUSE_PROJECTIONS:
+        # one projection GEMM for q,k,v (and one for gate,up below): the weights stay separate parameters with
+        # their HF names; the concatenation is an 8 MB copy whose backward hands each its gradient slice
+        qkv = F.linear(h, torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0),
+                       torch.cat([bq, bk, bv]) if bq is not None else None).view(T, Hq + 2 * Hkv, D)
+        q, k, v = qkv.split([Hq, Hkv, Hkv], dim=1)            # split's backward is ONE concatenation
+    else:
+        q = F.linear(h, a.q_proj.weight, bq).view(T, Hq, D)
+        k = F.linear(h, a.k_proj.weight, bk).view(T, Hkv, D)
+        v = F.linear(h, a.v_proj.weight, bv).view(T, Hkv, D)
     qn = getattr(a, "q_norm", None); kn = getattr(a, "k_norm", None)
     q = ops.qk_norm_rope(q, qn.weight if qn is not None else None, cos_sin, eps)
     k = ops.qk_norm_rope(k, kn.weight if kn is not None else None, cos_sin, eps)
@@ -125,7 +135,11 @@ def _layer_forward(layer, x, cos_sin, meta, Hq, Hkv, D, eps):
     x = x + F.linear(o.reshape(T, Hq * D), a.o_proj.weight)
     h = ops.rms_norm(x, layer.post_attention_layernorm.weight, eps)
     m = layer.mlp
-    x = x + F.linear(ops.swiglu(F.linear(h, m.gate_proj.weight), F.linear(h, m.up_proj.weight)), m.down_proj.weight)
+    if FUSE_PROJECTIONS:
+        act = ops.swiglu_fused(F.linear(h, torch.cat([m.gate_proj.weight, m.up_proj.weight], dim=0)))
+    else:
+        act = ops.swiglu(F.linear(h, m.gate_proj.weight), F.linear(h, m.up_proj.weight))
+    x = x + F.linear(act, m.down_proj.weight)
     return x
 
 

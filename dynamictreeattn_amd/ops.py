@@ -74,16 +74,14 @@ def attn_fwd_raw(q, k, v, meta: TreeAttnMeta, scale: float):
     _require_cuda(q, k, v)
     Tq, Hq, D = q.shape
     Tk, Hkv, _ = k.shape
-    if k.stride() != v.stride():
-        v = v.contiguous(); k = k.contiguous()
     out = torch.empty((Tq, Hq, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device)          # head-major: rows of one head are contiguous
-    (qs, qh), (ks, kh), (os_, oh) = _strides(q), _strides(k), _strides(out)
+    (qs, qh), (ks, kh), (vs, vh), (os_, oh) = _strides(q), _strides(k), _strides(v), _strides(out)
     tm = KernelTimer.active
     if tm is not None:
         ev = tm.span("fwd"); ev[0].record()
     st = lib().dta_tree_attn_fwd_ex(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(meta.subtree_end), ptr(meta.run_ptr), ptr(meta.runs),
-                                    Tq, Tk, meta.q_offset, Hq, Hkv, D, qs, qh, ks, kh, os_, oh, float(scale), _DT[q.dtype], _stream())
+                                    Tq, Tk, meta.q_offset, Hq, Hkv, D, qs, qh, ks, kh, vs, vh, os_, oh, float(scale), _DT[q.dtype], _stream())
     if tm is not None:
         ev[1].record()
     check(st, "dta_tree_attn_fwd")
@@ -99,7 +97,7 @@ def attn_bwd_raw(q, k, v, out, dout, lse, meta: TreeAttnMeta, scale: float, dk=N
     if dk is None:
         dk = torch.empty((Tk, Hkv, D), dtype=q.dtype, device=q.device); dv = torch.empty_like(dk)
     delta = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device)
-    (qs, qh), (ks, kh), (os_, oh), (dqs, dqh), (dks, dkh) = _strides(q), _strides(k), _strides(out), _strides(dq), _strides(dk)
+    (qs, qh), (ks, kh), (vs, vh), (os_, oh), (dqs, dqh), (dks, dkh) = _strides(q), _strides(k), _strides(v), _strides(out), _strides(dq), _strides(dk)
     units, splits = meta.dkv_units, meta.dkv_splits
     n_units = units.shape[0] if units is not None else 0
     n_splits = splits.shape[0] if splits is not None else 0
@@ -108,7 +106,7 @@ def attn_bwd_raw(q, k, v, out, dout, lse, meta: TreeAttnMeta, scale: float, dk=N
     def launch(which):
         return lib().dta_tree_attn_bwd_ex(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                                           ptr(meta.subtree_end), ptr(meta.run_ptr), ptr(meta.runs), ptr(meta.ktile_qend),
-                                          Tq, Tk, meta.q_offset, Hq, Hkv, D, qs, qh, ks, kh, os_, oh, dqs, dqh, dks, dkh,
+                                          Tq, Tk, meta.q_offset, Hq, Hkv, D, qs, qh, ks, kh, vs, vh, os_, oh, dqs, dqh, dks, dkh,
                                           float(scale), _DT[q.dtype], 1 if accumulate else 0, which,
                                           ptr(units), n_units, ptr(splits) if n_splits else None, n_splits, ptr(ws), _stream())
     tm = KernelTimer.active
@@ -335,23 +333,45 @@ def rope_cos_sin(depth: torch.Tensor, D: int, theta: float) -> torch.Tensor:
 
 
 class _SwiGLU(torch.autograd.Function):
+    """y = silu(gate) * up.  `gu` is either the fused [rows, 2C] projection output (gate | up) or None with
+    separate contiguous gate/up."""
+
     @staticmethod
-    def forward(ctx, g, u):
-        _require_cuda(g, u)
-        g = g.contiguous(); u = u.contiguous()
-        y = torch.empty_like(g)
-        check(lib().dta_swiglu_fwd(ptr(g), ptr(u), ptr(y), g.numel(), _DT[g.dtype], _stream()), "dta_swiglu_fwd")
+    def forward(ctx, gu, g, u):
+        if gu is not None:
+            _require_cuda(gu)
+            gu = gu if gu.stride(-1) == 1 and gu.dim() == 2 else gu.contiguous().view(-1, gu.shape[-1])
+            C = gu.shape[1] // 2
+            g, u, ld = gu[:, :C], gu[:, C:], gu.stride(0)
+        else:
+            _require_cuda(g, u)
+            g = g.contiguous().view(-1, g.shape[-1]); u = u.contiguous().view(-1, u.shape[-1])
+            C, ld = g.shape[1], g.shape[1]
+        rows = g.shape[0]
+        y = torch.empty((rows, C), dtype=g.dtype, device=g.device)
+        check(lib().dta_swiglu_fwd(ptr(g), ptr(u), ptr(y), rows, C, ld, _DT[g.dtype], _stream()), "dta_swiglu_fwd")
         ctx.save_for_backward(g, u)
+        ctx.fused, ctx.ld = gu is not None, ld
         return y
 
     @staticmethod
     def backward(ctx, dy):
         g, u = ctx.saved_tensors
+        rows, C = g.shape
         dy = dy.contiguous()
-        dg, du = torch.empty_like(g), torch.empty_like(u)
-        check(lib().dta_swiglu_bwd(ptr(g), ptr(u), ptr(dy), ptr(dg), ptr(du), g.numel(), _DT[g.dtype], _stream()), "dta_swiglu_bwd")
-        return dg, du
+        if ctx.fused:
+            dgu = torch.empty((rows, 2 * C), dtype=g.dtype, device=g.device)
+            dg, du, ldg = dgu[:, :C], dgu[:, C:], 2 * C
+        else:
+            dg, du, ldg = torch.empty_like(g), torch.empty_like(u), C
+        check(lib().dta_swiglu_bwd(ptr(g), ptr(u), ptr(dy), ptr(dg), ptr(du), rows, C, ctx.ld, ldg, _DT[g.dtype], _stream()), "dta_swiglu_bwd")
+        return (dgu, None, None) if ctx.fused else (None, dg, du)
 
 
 def swiglu(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
-    return _SwiGLU.apply(g, u)
+    return _SwiGLU.apply(None, g, u)
+
+
+def swiglu_fused(gu: torch.Tensor) -> torch.Tensor:
+    """gu [rows, 2C] = (gate | up) of one fused projection GEMM -> silu(gate) * up  [rows, C]."""
+    return _SwiGLU.apply(gu, None, None)

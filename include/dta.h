@@ -100,7 +100,8 @@ int dta_tree_attn_fwd(const void* q, const void* k, const void* v, void* out, fl
 int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse,
                          const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
                          int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
-                         int64_t q_stride_t, int64_t q_stride_h, int64_t kv_stride_t, int64_t kv_stride_h,
+                         int64_t q_stride_t, int64_t q_stride_h, int64_t k_stride_t, int64_t k_stride_h,
+                         int64_t v_stride_t, int64_t v_stride_h,
                          int64_t o_stride_t, int64_t o_stride_h, float scale, int32_t dtype, void* stream);
 
 /* Backward.  Two launches on `stream`: (1) per query tile: delta = rowsum(dout*out), dq;
@@ -124,7 +125,8 @@ int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v, const void
                          const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
                          const int32_t* ktile_qend,
                          int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
-                         int64_t q_stride_t, int64_t q_stride_h, int64_t kv_stride_t, int64_t kv_stride_h,
+                         int64_t q_stride_t, int64_t q_stride_h, int64_t k_stride_t, int64_t k_stride_h,
+                         int64_t v_stride_t, int64_t v_stride_h,
                          int64_t o_stride_t, int64_t o_stride_h, int64_t dq_stride_t, int64_t dq_stride_h,
                          int64_t dkv_stride_t, int64_t dkv_stride_h,
                          float scale, int32_t dtype, int32_t accumulate,
@@ -167,8 +169,11 @@ int dta_qk_norm_rope_bwd_blocks(int64_t n_heads_total);   /* rows of dw_partial 
 int dta_qk_norm_rope_bwd(const void* x, const void* w, const float* cos_sin, const void* dy, const float* rstd,
                          void* dx, float* dw_partial, int32_t T, int32_t NH, int32_t head_dim,
                          int64_t x_stride_t, int64_t dy_stride_t, int64_t dy_stride_h, int32_t dtype, void* stream);
-int dta_swiglu_fwd(const void* gate, const void* up, void* y, int64_t n, int32_t dtype, void* stream);
-int dta_swiglu_bwd(const void* gate, const void* up, const void* dy, void* dgate, void* dup, int64_t n, int32_t dtype, void* stream);
+/* gate/up: [rows, cols] with `ld` elements between rows (they may be the two halves of one fused [rows, 2*cols]
+ * projection output); y/dy: [rows, cols] contiguous; dgate/dup: `ld_grad` between rows. */
+int dta_swiglu_fwd(const void* gate, const void* up, void* y, int64_t rows, int32_t cols, int64_t ld, int32_t dtype, void* stream);
+int dta_swiglu_bwd(const void* gate, const void* up, const void* dy, void* dgate, void* dup,
+                   int64_t rows, int32_t cols, int64_t ld, int64_t ld_grad, int32_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

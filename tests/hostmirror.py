@@ -83,6 +83,11 @@ def _cpu_swiglu(g, u):
     return torch.nn.functional.silu(g) * u
 
 
+def _cpu_swiglu_fused(gu):
+    C = gu.shape[-1] // 2
+    return torch.nn.functional.silu(gu[..., :C]) * gu[..., C:]
+
+
 def install(monkeypatch):
     from dynamictreeattn_amd import ops, token_trie, tree_training_engine
     monkeypatch.setattr(token_trie, "_device_trie_arrays", _cpu_trie_arrays)
@@ -92,3 +97,4 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "rms_norm", _cpu_rms_norm)
     monkeypatch.setattr(ops, "qk_norm_rope", _cpu_qk_norm_rope)
     monkeypatch.setattr(ops, "swiglu", _cpu_swiglu)
+    monkeypatch.setattr(ops, "swiglu_fused", _cpu_swiglu_fused)

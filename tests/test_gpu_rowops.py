@@ -57,3 +57,4 @@ def test_swiglu(shape, dtype):
     g = torch.Generator().manual_seed(shape[0])
     a, b = torch.randn(*shape, generator=g) * 2, torch.randn(*shape, generator=g)
     _pair(ops.swiglu, hostmirror._cpu_swiglu, [a, b], dtype)
+    _pair(ops.swiglu_fused, hostmirror._cpu_swiglu_fused, [torch.cat([a, b], dim=-1)], dtype)
