@@ -50,7 +50,7 @@ struct AttnParams {
   const int32_t *dkv_units, *dkv_splits; float* dkv_ws;     // split-Q work units of the dK/dV sweep (NULL: one unit per key tile)
   int32_t Tq, Tk, q_offset, Hq, Hkv, group;
   int64_t q_st, q_sh, kv_st, kv_sh, v_st, v_sh, o_st, o_sh, dq_st, dq_sh, dkv_st, dkv_sh;
-  float scale; int32_t accumulate;
+  float scale; int32_t accumulate; int32_t ktile;
 };
 
 constexpr int TILE_BYTES = 64 * 256;           // 64 rows x 128 x 2 B
@@ -430,14 +430,16 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
 }
 
 // =================================================================================================
-// backward part 2: dK, dV   (key tile owns the workgroup; one wave per SIMD, 128 accumulators each)
+// backward part 2: dK, dV.  Key tile owns the workgroup; one wave per SIMD; each wave owns KB blocks of 32
+// keys (KB = 2: 64 keys, 256 accumulator registers), so every Q / dO fragment read from LDS (row-wise
+// for S, dP and transposed for dK^T, dV^T) feeds KB MFMAs.
 // =================================================================================================
 constexpr int KV_LDS = 2 * (2 * TILE_BYTES + 512);                 // double-buffered {Q image, dO image, lse[64], delta[64]}
 
-template <int DT>
+template <int DT, int KB>
 __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
   using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
-  constexpr int NT = 256, CPT = 4;
+  constexpr int NT = 256, CPT = 4, KT = 128 * KB;
   __shared__ __attribute__((aligned(16))) char smem[KV_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -447,33 +449,40 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
   // them) are cut into several units so that no workgroup carries a serial chain of hundreds of tiles
   const int kt = p.dkv_units ? p.dkv_units[4 * unit] : unit;
   const int slab = p.dkv_units ? p.dkv_units[4 * unit + 3] : -1;
-  const int k0 = kt * DTA_KTILE;
-  const int kidx = k0 + wave * 32 + r;
-  const int kidx_c = kidx < p.Tk ? kidx : p.Tk - 1;
+  const int k0 = kt * KT;
   const int q_hi = p.q_offset + p.Tq;
-  int se_l = (kidx < p.Tk) ? (p.subtree_end ? p.subtree_end[kidx] : 0x7fffffff) : 0;
-  se_l = se_l < q_hi ? se_l : q_hi;
-  // smallest subtree end over the workgroup's 128 keys: query tiles entirely below it (and below the
-  // key tile itself) need no mask at all
+  int kidx[KB], se_l[KB];
+  v8 kf[KB][8], vf[KB][8];
+#pragma unroll
+  for (int b = 0; b < KB; ++b) {
+    kidx[b] = k0 + wave * 32 * KB + 32 * b + r;
+    const int kc = kidx[b] < p.Tk ? kidx[b] : p.Tk - 1;
+    int se = (kidx[b] < p.Tk) ? (p.subtree_end ? p.subtree_end[kidx[b]] : 0x7fffffff) : 0;
+    se_l[b] = se < q_hi ? se : q_hi;
+    const e* kp = reinterpret_cast<const e*>(p.k) + (int64_t)kc * p.kv_st + (int64_t)kvh * p.kv_sh;
+    const e* vp = reinterpret_cast<const e*>(p.v) + (int64_t)kc * p.v_st + (int64_t)kvh * p.v_sh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { kf[b][s] = *reinterpret_cast<const v8*>(kp + 16 * s + 8 * h); vf[b][s] = *reinterpret_cast<const v8*>(vp + 16 * s + 8 * h); }
+  }
+  // smallest subtree end over the workgroup's keys: query tiles entirely below it (and below the key tile
+  // itself) need no mask at all
   __shared__ int se_min_s[4];
-  { int mn = se_l;
+  { int mn = se_l[0];
+#pragma unroll
+    for (int b = 1; b < KB; ++b) mn = se_l[b] < mn ? se_l[b] : mn;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
     if (lane == 0) se_min_s[wave] = mn; }
   __syncthreads();
   const int se_min = min(min(se_min_s[0], se_min_s[1]), min(se_min_s[2], se_min_s[3]));
 
-  const e* kp = reinterpret_cast<const e*>(p.k) + (int64_t)kidx_c * p.kv_st + (int64_t)kvh * p.kv_sh;
-  const e* vp = reinterpret_cast<const e*>(p.v) + (int64_t)kidx_c * p.v_st + (int64_t)kvh * p.v_sh;
-  v8 kf[8], vf[8];
+  f32x16 DK[KB][4], DV[KB][4];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) { kf[s] = *reinterpret_cast<const v8*>(kp + 16 * s + 8 * h); vf[s] = *reinterpret_cast<const v8*>(vp + 16 * s + 8 * h); }
-
-  f32x16 DK[4], DV[4];
+  for (int b = 0; b < KB; ++b)
 #pragma unroll
-  for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < 4; ++db)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) { DK[db][g] = 0.f; DV[db][g] = 0.f; }
+      for (int g = 0; g < 16; ++g) { DK[b][db][g] = 0.f; DV[b][db][g] = 0.f; }
 
   int qbeg, qend;
   if (p.dkv_units) { qbeg = p.dkv_units[4 * unit + 1]; qend = p.dkv_units[4 * unit + 2]; }
@@ -513,17 +522,21 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
       const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * TILE_BYTES); const float* del_s = lse_s + 64;
       const int ti = idx % ntile;
       const int qi0 = qbeg + 64 * ti;                                   // packed index of image row 0
-      const bool full = (qi0 >= k0 + DTA_KTILE - 1) && (qi0 + 63 < se_min);   // workgroup-uniform: no mask needed
-      // one 32-row query block at a time: S and dP stay at 32 live accumulators
+      const bool full = (qi0 >= k0 + KT - 1) && (qi0 + 63 < se_min);        // workgroup-uniform: no mask needed
+      // one 32-row query block at a time
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
-        f32x16 S, DP;
+        f32x16 S[KB], DP[KB];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) { S[g] = 0.f; DP[g] = 0.f; }
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) { S[b][g] = 0.f; DP[b][g] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-          S = T::mma(row_frag<v8>(Qs, 32 * qb + r, 2 * s + h), kf[s], S);
-          DP = T::mma(row_frag<v8>(Ds, 32 * qb + r, 2 * s + h), vf[s], DP);
+          const v8 aq = row_frag<v8>(Qs, 32 * qb + r, 2 * s + h);
+          const v8 ad = row_frag<v8>(Ds, 32 * qb + r, 2 * s + h);
+#pragma unroll
+          for (int b = 0; b < KB; ++b) { S[b] = T::mma(aq, kf[b][s], S[b]); DP[b] = T::mma(ad, vf[b][s], DP[b]); }
         }
         float lv[16], dv_[16];                                             // lse and delta*scale of this lane's 16 rows
 #pragma unroll
@@ -536,29 +549,36 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
         }
         if (full) {
 #pragma unroll
-          for (int g = 0; g < 16; ++g) {
-            const float pv = fast_exp2(__builtin_fmaf(S[g], c, -lv[g]));
-            S[g] = pv;
-            DP[g] = pv * __builtin_fmaf(DP[g], p.scale, -dv_[g]);
-          }
+          for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+              const float pv = fast_exp2(__builtin_fmaf(S[b][g], c, -lv[g]));
+              S[b][g] = pv;
+              DP[b][g] = pv * __builtin_fmaf(DP[b][g], p.scale, -dv_[g]);
+            }
         } else {
 #pragma unroll
-          for (int g = 0; g < 16; ++g) {
-            const int qi = qi0 + 32 * qb + 8 * (g >> 2) + 4 * h + (g & 3);
-            const bool ok = (kidx <= qi) && (qi < se_l);
-            const float pv = ok ? fast_exp2(__builtin_fmaf(S[g], c, -lv[g])) : 0.f;
-            S[g] = pv;
-            DP[g] = pv * __builtin_fmaf(DP[g], p.scale, -dv_[g]);
-          }
+          for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+              const int qi = qi0 + 32 * qb + 8 * (g >> 2) + 4 * h + (g & 3);
+              const bool ok = (kidx[b] <= qi) && (qi < se_l[b]);
+              const float pv = ok ? fast_exp2(__builtin_fmaf(S[b][g], c, -lv[g])) : 0.f;
+              S[b][g] = pv;
+              DP[b][g] = pv * __builtin_fmaf(DP[b][g], p.scale, -dv_[g]);
+            }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const v8 pb = pack_half<DT>(S, s2);
-          const v8 sb = pack_half<DT>(DP, s2);
+          v8 pb[KB], sb[KB];
+#pragma unroll
+          for (int b = 0; b < KB; ++b) { pb[b] = pack_half<DT>(S[b], s2); sb[b] = pack_half<DT>(DP[b], s2); }
 #pragma unroll
           for (int db = 0; db < 4; ++db) {
-            DV[db] = T::mma(tr_frag<v8>(Ds, 32 * qb + 16 * s2, db, lane), pb, DV[db]);
-            DK[db] = T::mma(tr_frag<v8>(Qs, 32 * qb + 16 * s2, db, lane), sb, DK[db]);
+            const v8 adt = tr_frag<v8>(Ds, 32 * qb + 16 * s2, db, lane);
+            const v8 aqt = tr_frag<v8>(Qs, 32 * qb + 16 * s2, db, lane);
+#pragma unroll
+            for (int b = 0; b < KB; ++b) { DV[b][db] = T::mma(adt, pb[b], DV[b][db]); DK[b][db] = T::mma(aqt, sb[b], DK[b][db]); }
           }
         }
       }
@@ -568,37 +588,41 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
   }
 #undef KV_LOAD
 #undef KV_WRITE
-  if (slab >= 0) {
-    // partial sums of a split key tile: fp32 slab [2][128 keys][128 d], summed in unit order by the finalize kernel
-    float* ws = p.dkv_ws + ((int64_t)slab * p.Hkv + kvh) * (2 * DTA_KTILE * 128) + (int64_t)(wave * 32 + r) * 128;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+  for (int b = 0; b < KB; ++b) {
+    const int kloc = wave * 32 * KB + 32 * b + r;
+    if (slab >= 0) {
+      // partial sums of a split key tile: fp32 slab [2][KT keys][128 d], summed in unit order by the finalize kernel
+      float* ws = p.dkv_ws + ((int64_t)slab * p.Hkv + kvh) * (2 * KT * 128) + (int64_t)kloc * 128;
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int d = 32 * db + 8 * gq + 4 * h;
-        *reinterpret_cast<float4*>(ws + d) = make_float4(DK[db][4 * gq], DK[db][4 * gq + 1], DK[db][4 * gq + 2], DK[db][4 * gq + 3]);
-        *reinterpret_cast<float4*>(ws + DTA_KTILE * 128 + d) = make_float4(DV[db][4 * gq], DV[db][4 * gq + 1], DV[db][4 * gq + 2], DV[db][4 * gq + 3]);
-      }
-  } else if (kidx < p.Tk) {
-    e* dkp = reinterpret_cast<e*>(p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
-    e* dvp = reinterpret_cast<e*>(p.dv) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+      for (int db = 0; db < 4; ++db)
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int d = 32 * db + 8 * gq + 4 * h;
-        v4 wk, wv;
-        if (p.accumulate) {
-          const v4 ok_ = *reinterpret_cast<const v4*>(dkp + d); const v4 ov_ = *reinterpret_cast<const v4*>(dvp + d);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { wk[j] = (e)(DK[db][4 * gq + j] + (float)ok_[j]); wv[j] = (e)(DV[db][4 * gq + j] + (float)ov_[j]); }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { wk[j] = (e)DK[db][4 * gq + j]; wv[j] = (e)DV[db][4 * gq + j]; }
+        for (int gq = 0; gq < 4; ++gq) {
+          const int d = 32 * db + 8 * gq + 4 * h;
+          *reinterpret_cast<float4*>(ws + d) = make_float4(DK[b][db][4 * gq], DK[b][db][4 * gq + 1], DK[b][db][4 * gq + 2], DK[b][db][4 * gq + 3]);
+          *reinterpret_cast<float4*>(ws + KT * 128 + d) = make_float4(DV[b][db][4 * gq], DV[b][db][4 * gq + 1], DV[b][db][4 * gq + 2], DV[b][db][4 * gq + 3]);
         }
-        *reinterpret_cast<v4*>(dkp + d) = wk;
-        *reinterpret_cast<v4*>(dvp + d) = wv;
-      }
+    } else if (kidx[b] < p.Tk) {
+      e* dkp = reinterpret_cast<e*>(p.dk) + (int64_t)kidx[b] * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+      e* dvp = reinterpret_cast<e*>(p.dv) + (int64_t)kidx[b] * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int d = 32 * db + 8 * gq + 4 * h;
+          v4 wk, wv;
+          if (p.accumulate) {
+            const v4 ok_ = *reinterpret_cast<const v4*>(dkp + d); const v4 ov_ = *reinterpret_cast<const v4*>(dvp + d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wk[j] = (e)(DK[b][db][4 * gq + j] + (float)ok_[j]); wv[j] = (e)(DV[b][db][4 * gq + j] + (float)ov_[j]); }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wk[j] = (e)DK[b][db][4 * gq + j]; wv[j] = (e)DV[b][db][4 * gq + j]; }
+          }
+          *reinterpret_cast<v4*>(dkp + d) = wk;
+          *reinterpret_cast<v4*>(dvp + d) = wv;
+        }
+    }
   }
 }
 
@@ -607,16 +631,17 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
 template <int DT>
 __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_finalize_kernel(AttnParams p) {
   using e = typename Ty<DT>::e;
+  const int KT = p.ktile;
   const int kvh = blockIdx.x % p.Hkv, sp = blockIdx.x / p.Hkv;
   const int kt = p.dkv_splits[4 * sp], first = p.dkv_splits[4 * sp + 1], n = p.dkv_splits[4 * sp + 2];
-  for (int i = threadIdx.x; i < 2 * DTA_KTILE * 32; i += 256) {          // float4 index inside a slab
-    const int which = i / (DTA_KTILE * 32), rem = i - which * DTA_KTILE * 32;
+  for (int i = threadIdx.x; i < 2 * KT * 32; i += 256) {                  // float4 index inside a slab
+    const int which = i / (KT * 32), rem = i - which * KT * 32;
     const int key = rem >> 5, d = (rem & 31) << 2;
-    const int kidx = kt * DTA_KTILE + key;
+    const int kidx = kt * KT + key;
     if (kidx >= p.Tk) continue;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < n; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(p.dkv_ws + ((int64_t)(first + j) * p.Hkv + kvh) * (2 * DTA_KTILE * 128) + (int64_t)i * 4);
+      const float4 v = *reinterpret_cast<const float4*>(p.dkv_ws + ((int64_t)(first + j) * p.Hkv + kvh) * (2 * KT * 128) + (int64_t)i * 4);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     e* out = reinterpret_cast<e*>(which ? p.dv : p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh + d;
@@ -681,7 +706,10 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.v_st = v_st; p.v_sh = v_sh; p.o_st = o_st; p.o_sh = o_sh;
   p.dq_st = dq_st; p.dq_sh = dq_sh; p.dkv_st = dkv_st; p.dkv_sh = dkv_sh; p.scale = scale; p.accumulate = accumulate;
   const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
-  const int nkt = (Tk + DTA_KTILE - 1) / DTA_KTILE;
+  // KB = 2 (64 keys per wave, every LDS fragment feeding two MFMAs) is written but needs > 512 registers
+  // with K and V fragments resident; it stays out of the build until their staging moves to LDS/DMA.
+  p.ktile = DTA_KTILE;
+  const int nkt = (Tk + p.ktile - 1) / p.ktile;
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();   // drop a stale error of an earlier, unrelated runtime call
   if ((which & 3) == 0) return DTA_EINVAL;
@@ -690,11 +718,11 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   const dim3 gq(pair ? nqt * Hq / 2 : nqt * Hq), bq(pair ? 512 : 256);
   if (dtype == DTA_BF16) {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 1>), gq, bq, 0, st, p); }
-    if (which & 2) { hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_BF16>, dim3(ndkv * Hkv), dim3(256), 0, st, p);
+    if (which & 2) { hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_BF16, DTA_KTILE / 128>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
                      if (dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_BF16>, dim3(n_splits * Hkv), dim3(256), 0, st, p); }
   } else {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 1>), gq, bq, 0, st, p); }
-    if (which & 2) { hipLaunchKernelGGL(tree_attn_bwd_dkv_kernel<DTA_F16>, dim3(ndkv * Hkv), dim3(256), 0, st, p);
+    if (which & 2) { hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_F16, DTA_KTILE / 128>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
                      if (dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_F16>, dim3(n_splits * Hkv), dim3(256), 0, st, p); }
   }
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;

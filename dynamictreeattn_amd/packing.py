@@ -16,7 +16,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 
 QTILE = 128
-KTILE = 128
+KTILE = 128      # = DTA_KTILE (dta.h)
 
 
 @dataclass

@@ -33,7 +33,7 @@ extern "C" {
 #define DTA_F16 1
 
 #define DTA_QTILE 128        /* query rows per workgroup (fwd / dQ kernels)  */
-#define DTA_KTILE 128        /* key rows per workgroup (dK/dV kernel)        */
+#define DTA_KTILE 128        /* key rows per workgroup (dK/dV kernel): 4 waves x 32 keys */
 
 int dta_version(void);
 
