@@ -119,10 +119,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count()
+    local = local % max(n_dev, 1)               # rehearsal on a 1-GPU box: ranks share the card (gloo only, below)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") needs one GPU per rank; DTA_BENCH_BACKEND=gloo rehearses the N>1 code path on one GPU
+        backend = os.environ.get("DTA_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     cfg = synth.QWEN3_0P6B if args.model == "qwen3-0.6b" else synth.QWEN3_4B

@@ -125,3 +125,57 @@ def test_qwen3_0p6b_config1_tree_vs_dense_within_recorded_bound():
         assert abs(ld - ref["loss_dense"]) < 5e-3 * abs(ref["loss_dense"]) and abs(lt - ref["loss_tree"]) < 5e-3 * abs(ref["loss_tree"])
         for n, p in m.named_parameters():
             assert abs(float(p.grad.float().norm()) - ref["norm_dense"][n]) <= 0.08 * ref["norm_dense"][n] + 1e-4, n
+
+
+def test_hf_attention_interface_plugin_matches_eager():
+    """An unmodified transformers Qwen3 with attn_implementation="dta_mi355x" (prefix K/V through a
+    DynamicCache, as the reference engine calls it) against its own eager backend."""
+    transformers = pytest.importorskip("transformers")
+    from transformers.cache_utils import DynamicCache
+    from dynamictreeattn_amd import hf_attention
+    name = hf_attention.register()
+    cfg = synth.TINY_CFGS["d128"]
+    def build(impl):
+        c = transformers.Qwen3Config(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+                                     num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=128, tie_word_embeddings=True,
+                                     rope_parameters={"rope_type": "default", "rope_theta": 1e6})
+        c._attn_implementation = impl
+        m = transformers.Qwen3ForCausalLM(c)
+        w = mo.init_weights(cfg, seed=3)
+        m.load_state_dict({**w, "lm_head.weight": w["model.embed_tokens.weight"]}, strict=False)
+        return m.to(DEV).bfloat16().train()
+    g = torch.Generator().manual_seed(0)
+    toks = torch.randint(0, cfg["vocab_size"], (1, 300), generator=g).to(DEV)
+    outs = {}
+    for impl in ("eager", name):
+        m = build(impl)
+        with torch.no_grad():
+            first = m(toks[:, :171], use_cache=True)                                  # prefix
+        cache = first.past_key_values
+        out = m(toks[:, 171:], past_key_values=cache, use_cache=True)                 # 129 new tokens against 171 cached
+        out.logits.float().pow(2).mean().backward()
+        outs[impl] = (out.logits.float().detach(), m.model.layers[0].self_attn.q_proj.weight.grad.float().clone())
+    assert (outs["eager"][0] - outs[name][0]).abs().max() < 0.05 * outs["eager"][0].abs().max()
+    assert mo.grad_ratio(outs["eager"][1], outs[name][1]) < 5e-2
+
+
+def test_wide_deep_trie_fp16_with_layer_checkpointing():
+    """BASELINE config 5 shape at reduced size (8 branches x 4096 deep sharing a 256-token root, fp16):
+    deep paths (64 key tiles per query tile), forced per-layer recomputation and LM-head recomputation;
+    tree == dense on the same kernels."""
+    cfg = synth.TINY_CFGS["d128"]
+    m = Qwen3TreeLM.from_named(cfg, mo.init_weights(cfg, seed=5), DEV, torch.float16)
+    seqs = synth.as_tensors(synth.wide(seed=1, V=cfg["vocab_size"], root=256, branches=8, depth=4096))
+    att = lambda: [{"w_logprobs": -1.0, "w_entropy": 0.1} for _ in seqs]
+    t = TokenTrie(seqs, att()); t.backward_permute()
+    st = t.get_stats("backward", 2048)
+    assert st["n_tree_tokens"] == 256 + 8 * (4096 - 256)
+    e = TreeTrainingEngine(m.config, DEV, torch.float16, 4096)
+    e.checkpoint_layers = True
+    lt = e.backward(m, t, mo.default_loss, 2048)
+    gt = {n: p.grad.float().clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    ld = dense.backward(m, seqs, att(), mo.default_loss, act_ckpt=True)
+    assert abs(lt - ld) < 2e-3 * abs(ld)
+    ratios = [mo.grad_ratio(p.grad.float(), gt[n]) for n, p in m.named_parameters()]
+    assert max(ratios) < 2e-2, max(ratios)
