@@ -494,30 +494,34 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
   const int total = ntile * p.group;
   const float c = p.scale * LOG2E;
 
-  u32x4 qreg[CPT], dreg[CPT]; float lreg = 0.f, dlreg = 0.f;
-#define KV_LOAD(IDX)                                                                                       \
+  // Q / dO tiles go global -> LDS directly (LDS-DMA, no staging registers, no ds_write): a wave instruction
+  // lands 64 x 16 B = 4 image rows lane-linearly, so the XOR swizzle of the image is applied to the per-lane
+  // SOURCE chunk instead (the read side uses the same involution).  lse / delta*scale are 64 floats each and
+  // take the ordinary path BEFORE the DMA is issued (an ordinary load behind a DMA would drain it).
+#define KV_DMA(IDX, B)                                                                                     \
   { const int hg_ = (IDX) / ntile, ti_ = (IDX) - hg_ * ntile; const int hq_ = kvh * p.group + hg_;         \
     const int row0_ = qbeg + 64 * ti_ - p.q_offset;                                                        \
+    char* base_ = smem + (B) * (2 * TILE_BYTES + 512);                                                     \
+    if (tid < 128) { int qr_ = row0_ + (tid & 63); qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;                      \
+      reinterpret_cast<float*>(base_ + 2 * TILE_BYTES)[tid] =                                              \
+          tid < 64 ? p.lse_r[(int64_t)hq_ * p.Tq + qr_] : p.delta[(int64_t)hq_ * p.Tq + qr_] * p.scale; }   \
     const e* qb_ = reinterpret_cast<const e*>(p.q) + (int64_t)hq_ * p.q_sh;                                \
     const e* db_ = reinterpret_cast<const e*>(p.dout) + (int64_t)hq_ * p.o_sh;                             \
-    DTA_STAGE_LOAD(qreg, dreg, qb_, db_, p.q_st, p.o_st, row0_, p.Tq, NT, CPT)                             \
-    if (tid < 64) { int qr_ = row0_ + tid; qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;                              \
-      lreg = p.lse_r[(int64_t)hq_ * p.Tq + qr_]; dlreg = p.delta[(int64_t)hq_ * p.Tq + qr_] * p.scale; } }
-#define KV_WRITE(B)                                                                                        \
-  { char* base_ = smem + (B) * (2 * TILE_BYTES + 512);                                                     \
-    DTA_STAGE_WRITE(qreg, dreg, base_, base_ + TILE_BYTES, NT, CPT)                                        \
-    if (tid < 64) { reinterpret_cast<float*>(base_ + 2 * TILE_BYTES)[tid] = lreg; reinterpret_cast<float*>(base_ + 2 * TILE_BYTES)[64 + tid] = dlreg; } }
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
+      const int piece_ = wave * 4 + i_, row_ = 4 * piece_ + (lane >> 4);                                   \
+      const int ch_ = (lane & 15) ^ (((row_ & 3) << 2) | ((row_ >> 2) & 3));                                \
+      int qr_ = row0_ + row_; qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;                                           \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb_ + (int64_t)qr_ * p.q_st + ch_ * 8), \
+                                       (__attribute__((address_space(3))) void*)(base_ + piece_ * 1024), 16, 0, 0);            \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + (int64_t)qr_ * p.o_st + ch_ * 8), \
+                                       (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + piece_ * 1024), 16, 0, 0); } }
 
   if (total > 0) {
-    KV_LOAD(0) KV_WRITE(0)
-    if (total > 1) KV_LOAD(1)
-    __syncthreads();
+    KV_DMA(0, 0)
+    __syncthreads();                                 // hipcc drains the DMA (vmcnt(0)) in front of the barrier
     int cur = 0;
     for (int idx = 0; idx < total; ++idx) {
-      if (idx + 1 < total) {
-        KV_WRITE(cur ^ 1)
-        if (idx + 2 < total) KV_LOAD(idx + 2)
-      }
+      if (idx + 1 < total) KV_DMA(idx + 1, cur ^ 1)    // buffer cur^1 was last read before the previous barrier
       const char* Qs = smem + cur * (2 * TILE_BYTES + 512); const char* Ds = Qs + TILE_BYTES;
       const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * TILE_BYTES); const float* del_s = lse_s + 64;
       const int ti = idx % ntile;
@@ -586,8 +590,7 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
       cur ^= 1;
     }
   }
-#undef KV_LOAD
-#undef KV_WRITE
+#undef KV_DMA
 #pragma unroll
   for (int b = 0; b < KB; ++b) {
     const int kloc = wave * 32 * KB + 32 * b + r;
