@@ -191,8 +191,10 @@ def logprob_entropy_bwd_raw(logits, labels, lse, ent, g_lp, g_extra, g_ent, temp
 
 class _HeadRows(torch.autograd.Function):
     """(lp_next [T], lp_fork [F], ent [T]) from hidden rows: lp_next[r] = log p(next_tok[r] | row r),
-    lp_fork[f] = log p(fork_tok[f] | row fork_rows[f]).  Rows are processed `chunk` at a time; the
-    [chunk, V] logits are kept for backward when they fit `keep_bytes`, else recomputed."""
+    lp_fork[f] = log p(fork_tok[f] | row fork_rows[f]).  When the model-dtype [T, V] logits fit
+    `keep_bytes` they are produced by ONE GEMM, kept, turned into dLoss/dlogits IN PLACE in backward and
+    consumed by one dgrad and one wgrad GEMM.  Otherwise rows go `chunk` at a time and the logits of a
+    chunk are recomputed in backward (at most one [chunk, V] block alive)."""
 
     @staticmethod
     def forward(ctx, h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes):
@@ -200,23 +202,24 @@ class _HeadRows(torch.autograd.Function):
         dev = h.device
         V = W.shape[0]
         keep = T * V * h.element_size() <= keep_bytes
+        step = T if keep else chunk
         lse = torch.empty(T, dtype=torch.float32, device=dev)
         ent = torch.empty(T, dtype=torch.float32, device=dev) if want_entropy else None
         lp_next = torch.empty(T, dtype=torch.float32, device=dev)
         lp_fork = torch.empty(fork_rows.numel(), dtype=torch.float32, device=dev)
-        kept = []
-        for ci, a in enumerate(range(0, T, chunk)):
-            b = min(a + chunk, T)
+        kept = None
+        for ci, a in enumerate(range(0, T, step)):
+            b = min(a + step, T)
             logits = torch.mm(h[a:b], W.t())
             l, e, p = logprob_entropy_fwd_raw(logits, next_tok[a:b], want_entropy)
             lse[a:b] = l; lp_next[a:b] = p
             if want_entropy:
                 ent[a:b] = e
-            f0, f1 = fork_bounds[ci], fork_bounds[ci + 1]
+            f0, f1 = (0, fork_rows.numel()) if keep else (fork_bounds[ci], fork_bounds[ci + 1])
             if f1 > f0:
                 lp_fork[f0:f1] = logits[fork_rows[f0:f1] - a, fork_tok[f0:f1]].float() - l[fork_rows[f0:f1] - a]
             if keep:
-                kept.append(logits)
+                kept = logits
         ctx.save_for_backward(h, W, next_tok, fork_rows, fork_tok, lse, ent if want_entropy else lse)
         ctx.kept, ctx.chunk, ctx.fork_bounds, ctx.want_entropy = kept, chunk, fork_bounds, want_entropy
         return lp_next, lp_fork, (ent if want_entropy else lse.new_zeros(0))
@@ -225,27 +228,31 @@ class _HeadRows(torch.autograd.Function):
     def backward(ctx, g_next, g_fork, g_ent):
         h, W, next_tok, fork_rows, fork_tok, lse, ent = ctx.saved_tensors
         T = h.shape[0]
-        chunk, fb = ctx.chunk, ctx.fork_bounds
+        fb = ctx.fork_bounds
         g_next = g_next.contiguous().float()
         g_ent = g_ent.contiguous().float() if ctx.want_entropy else None
         g_fork = g_fork.contiguous().float()
         g_extra = None
         if fork_rows.numel():
             g_extra = torch.zeros(T, dtype=torch.float32, device=h.device).index_add_(0, fork_rows, g_fork)
+        kept = ctx.kept
+        step = T if kept is not None else ctx.chunk
         dh = torch.empty_like(h)
-        dW = torch.zeros(W.shape, dtype=torch.float32, device=W.device)
-        for ci, a in enumerate(range(0, T, chunk)):
-            b = min(a + chunk, T)
-            logits = ctx.kept[ci] if ctx.kept else torch.mm(h[a:b], W.t())
+        dW = None if kept is not None else torch.zeros(W.shape, dtype=torch.float32, device=W.device)
+        for ci, a in enumerate(range(0, T, step)):
+            b = min(a + step, T)
+            logits = kept if kept is not None else torch.mm(h[a:b], W.t())
             logprob_entropy_bwd_raw(logits, next_tok[a:b], lse[a:b], ent[a:b] if ctx.want_entropy else None, g_next[a:b],
                                     g_extra[a:b] if g_extra is not None else None, g_ent[a:b] if ctx.want_entropy else None)
-            f0, f1 = fb[ci], fb[ci + 1]
+            f0, f1 = (0, fork_rows.numel()) if kept is not None else (fb[ci], fb[ci + 1])
             if f1 > f0:
                 logits.index_put_((fork_rows[f0:f1] - a, fork_tok[f0:f1]), g_fork[f0:f1].to(logits.dtype), accumulate=True)
             torch.mm(logits, W, out=dh[a:b])
-            dW += torch.mm(logits.t(), h[a:b])
-            if ctx.kept:
-                ctx.kept[ci] = None
+            if kept is not None:
+                dW = torch.mm(logits.t(), h)                 # one wgrad GEMM over all T rows (fp32 accumulate inside)
+            else:
+                dW += torch.mm(logits.t(), h[a:b])
+        ctx.kept = None
         return dh, dW.to(W.dtype), None, None, None, None, None, None, None
 
 
