@@ -199,6 +199,19 @@ def main():
     attn_ms_total = ms["fwd"][0] + ms["bwd_dq"][0] + ms["bwd_dkv"][0]
     all_tf = (14 * Hq * D * pairs * L) / (attn_ms_total * 1e-3) / 1e12 if attn_ms_total > 0 else 0.0
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; take the latest
+    # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE result for the same kernel and trie shape (profiles/)
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_attn_traffic.json")))
+        if cand:
+            tj = json.load(open(cand[-1]))
+            traffic = tj["kernels"]["tree_attn_bwd_dkv_kernel"]["hbm_bytes_per_launch"]
+            traffic_src = os.path.relpath(cand[-1], ROOT) + " (tau2 seed-0 trie, one layer; 2*FETCH_SIZE+WRITE_SIZE)"
+    except Exception:
+        pass
+
     out = {
         "metric": "tree-attn fwd+bwd tokens/sec, Qwen3-0.6B tau2-16k tries", "value": n_tokens / wall, "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -209,7 +222,7 @@ def main():
                    "grad_allreduce": "RCCL sum" if world > 1 else "none"},
         "tree_tokens_per_s": n_tree / wall,
         "roofline": {"bound": "mfma", "kernel": "tree_attn_bwd_dkv_kernel", "achieved": dkv_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": dkv_tf / PEAK_BF16_TFLOPS, "traffic": None, "avg_launch_ms": dkv_ms,
+                     "frac": dkv_tf / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dkv_ms,
                      "flops_per_pair_per_layer": 8 * Hq * D, "pairs_per_step": pairs / max(args.steps, 1),
                      "other_kernels": {"tree_attn_fwd_kernel": {"achieved": fwd_tf, "avg_launch_ms": fwd_ms, "flops_per_pair_per_layer": 4 * Hq * D},
                                        "tree_attn_bwd_dq_kernel": {"achieved": dq_tf, "avg_launch_ms": dq_ms, "flops_per_pair_per_layer": 2 * Hq * D},
