@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
   }
   const int ntile = qend > qbeg ? (qend - qbeg + 63) / 64 : 0;
   const int total = ntile * p.group;
-  const float c = p.scale * LOG2E;
+  const float c = p.scale * LOG2E, inv_c = 1.f / c;
 
   // Q / dO tiles go global -> LDS directly (LDS-DMA, no staging registers, no ds_write): a wave instruction
   // lands 64 x 16 B = 4 image rows lane-linearly, so the XOR swizzle of the image is applied to the per-lane
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
     char* base_ = smem + (B) * (2 * TILE_BYTES + 512);                                                     \
     if (tid < 128) { int qr_ = row0_ + (tid & 63); qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;                      \
       reinterpret_cast<float*>(base_ + 2 * TILE_BYTES)[tid] =                                              \
-          tid < 64 ? p.lse_r[(int64_t)hq_ * p.Tq + qr_] : p.delta[(int64_t)hq_ * p.Tq + qr_] * p.scale; }   \
+          tid < 64 ? -p.lse_r[(int64_t)hq_ * p.Tq + qr_] * inv_c : -p.delta[(int64_t)hq_ * p.Tq + qr_]; }     \
     const e* qb_ = reinterpret_cast<const e*>(p.q) + (int64_t)hq_ * p.q_sh;                                \
     const e* db_ = reinterpret_cast<const e*>(p.dout) + (int64_t)hq_ * p.o_sh;                             \
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
@@ -530,11 +530,20 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
       // one 32-row query block at a time
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
+        // row constants as the INITIAL accumulators: S starts at -lse/c and dP at -delta, so after the MFMA
+        // chains  p = exp2(c*S)  and  dS = p*dP*scale  need no per-row operands in registers
         f32x16 S[KB], DP[KB];
 #pragma unroll
-        for (int b = 0; b < KB; ++b)
+        for (int gq = 0; gq < 4; ++gq) {
+          const int ql = 32 * qb + 8 * gq + 4 * h;
+          const float4 l4 = *reinterpret_cast<const float4*>(lse_s + ql);
+          const float4 d4 = *reinterpret_cast<const float4*>(del_s + ql);
 #pragma unroll
-          for (int g = 0; g < 16; ++g) { S[b][g] = 0.f; DP[b][g] = 0.f; }
+          for (int b = 0; b < KB; ++b) {
+            S[b][4 * gq] = l4.x; S[b][4 * gq + 1] = l4.y; S[b][4 * gq + 2] = l4.z; S[b][4 * gq + 3] = l4.w;
+            DP[b][4 * gq] = d4.x; DP[b][4 * gq + 1] = d4.y; DP[b][4 * gq + 2] = d4.z; DP[b][4 * gq + 3] = d4.w;
+          }
+        }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
           const v8 aq = row_frag<v8>(Qs, 32 * qb + r, 2 * s + h);
@@ -542,23 +551,14 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
           for (int b = 0; b < KB; ++b) { S[b] = T::mma(aq, kf[b][s], S[b]); DP[b] = T::mma(ad, vf[b][s], DP[b]); }
         }
-        float lv[16], dv_[16];                                             // lse and delta*scale of this lane's 16 rows
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int ql = 32 * qb + 8 * gq + 4 * h;
-          const float4 l4 = *reinterpret_cast<const float4*>(lse_s + ql);
-          const float4 d4 = *reinterpret_cast<const float4*>(del_s + ql);
-          lv[4 * gq] = l4.x; lv[4 * gq + 1] = l4.y; lv[4 * gq + 2] = l4.z; lv[4 * gq + 3] = l4.w;
-          dv_[4 * gq] = d4.x; dv_[4 * gq + 1] = d4.y; dv_[4 * gq + 2] = d4.z; dv_[4 * gq + 3] = d4.w;
-        }
         if (full) {
 #pragma unroll
           for (int b = 0; b < KB; ++b)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-              const float pv = fast_exp2(__builtin_fmaf(S[b][g], c, -lv[g]));
+              const float pv = fast_exp2(S[b][g] * c);
               S[b][g] = pv;
-              DP[b][g] = pv * __builtin_fmaf(DP[b][g], p.scale, -dv_[g]);
+              DP[b][g] = pv * DP[b][g] * p.scale;
             }
         } else {
 #pragma unroll
@@ -567,9 +567,9 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
             for (int g = 0; g < 16; ++g) {
               const int qi = qi0 + 32 * qb + 8 * (g >> 2) + 4 * h + (g & 3);
               const bool ok = (kidx[b] <= qi) && (qi < se_l[b]);
-              const float pv = ok ? fast_exp2(__builtin_fmaf(S[b][g], c, -lv[g])) : 0.f;
+              const float pv = ok ? fast_exp2(S[b][g] * c) : 0.f;
               S[b][g] = pv;
-              DP[b][g] = pv * __builtin_fmaf(DP[b][g], p.scale, -dv_[g]);
+              DP[b][g] = pv * DP[b][g] * p.scale;
             }
         }
 #pragma unroll
