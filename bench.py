@@ -2,8 +2,8 @@
 """bench.py — tree-attn fwd+bwd tokens/s, Qwen3-0.6B bf16, synthetic tau2-16k-shaped tries.
 
 One *step* = one pass of the hot path over one batch: every rank takes one bin of the global batch
-(N_ranks tau2-shaped calls merged and partitioned by ``LB_by_DFS_and_TM``, as data_parallel.py does
-offline), builds its TokenTrie (HIP LCP/leafization), permutes it for backward, runs
+(N_ranks tau2-shaped calls merged and partitioned by ``LB_by_DFS_and_TM`` before the clock starts, as
+data_parallel.py does offline), builds its TokenTrie (HIP LCP/leafization), permutes it for backward, runs
 ``TreeTrainingEngine.backward`` (HIP tree attention fwd+bwd inside the full model pass) and the
 ranks sum their parameter gradients with one RCCL all-reduce.  Timed sync-to-sync like run.py:90-108;
 metric = Σ original-sequence tokens / wall (run_all.py:156-159), MAX over ranks.
@@ -146,8 +146,12 @@ def main():
 
     stats_acc = {"n_tokens": 0, "n_tree_tokens": 0, "pairs": 0}
 
-    def step(seqs, timed: bool):
-        mine = [seqs[i] for i in dp.my_bin(seqs, rank, world, "backward", args.block_size)]
+    # The partition is OFFLINE in the reference (data_parallel.py writes {name}_bin{k}.pt ahead of the runs,
+    # exp/exp_dp.py:43-49) and its timed region is trie build + permute + engine call per bin (run.py:90-108):
+    # same here — bins are planned before the clock starts, everything from TokenTrie(...) on is timed.
+    my_seqs = [[seqs[i] for i in dp.my_bin(seqs, rank, world, "backward", args.block_size)] for seqs in batches]
+
+    def step(mine, timed: bool):
         model.zero_grad(set_to_none=True)
         trie = TokenTrie(mine, [dict(ATTACH) for _ in mine])
         trie.backward_permute()
@@ -161,7 +165,7 @@ def main():
         return loss
 
     for s in range(args.warmup):
-        step(batches[s], False)
+        step(my_seqs[s], False)
         model.zero_grad(set_to_none=True)
 
     timer = ops.KernelTimer()
@@ -171,7 +175,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.time()
     for s in range(args.warmup, total_steps):
-        step(batches[s], True)
+        step(my_seqs[s], True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -436,13 +436,17 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
 // =================================================================================================
 constexpr int KV_LDS = 2 * (2 * TILE_BYTES + 512);                 // double-buffered {Q image, dO image, lse[64], delta[64]}
 
-template <int DT, int KB>
-__global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
+template <int DT, int KB, int NG>
+__global__ __launch_bounds__(256 * NG) void tree_attn_bwd_dkv_kernel(AttnParams p) {
   using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
-  constexpr int NT = 256, CPT = 4, KT = 128 * KB;
-  __shared__ __attribute__((aligned(16))) char smem[KV_LDS];
+  constexpr int KT = 128 * KB;
+  __shared__ __attribute__((aligned(16))) char smem_all[NG * KV_LDS];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  // NG = 2: two groups of 4 waves (two waves per SIMD) own the SAME keys and take alternate items of the
+  // (query head, query tile) sweep through their own double-buffered Q/dO images; their partial dK/dV are
+  // summed through LDS at the end in a fixed order.
+  const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  char* smem = smem_all + grp * KV_LDS;
   const int bid = blockIdx.x;
   const int kvh = bid % p.Hkv; const int unit = bid / p.Hkv;
   // a unit = (key tile, packed query range, slab): heavy key tiles (root-side: every query below them sees
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
     for (int b = 1; b < KB; ++b) mn = se_l[b] < mn ? se_l[b] : mn;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
-    if (lane == 0) se_min_s[wave] = mn; }
+    if (lane == 0 && grp == 0) se_min_s[wave] = mn; }
   __syncthreads();
   const int se_min = min(min(se_min_s[0], se_min_s[1]), min(se_min_s[2], se_min_s[3]));
 
@@ -516,12 +520,15 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + (int64_t)qr_ * p.o_st + ch_ * 8), \
                                        (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + piece_ * 1024), 16, 0, 0); } }
 
-  if (total > 0) {
-    KV_DMA(0, 0)
+  const int niter = (total + NG - 1) / NG;               // same barrier count in every group
+  {
+    if (grp < total) KV_DMA(grp, 0)
     __syncthreads();                                 // hipcc drains the DMA (vmcnt(0)) in front of the barrier
     int cur = 0;
-    for (int idx = 0; idx < total; ++idx) {
-      if (idx + 1 < total) KV_DMA(idx + 1, cur ^ 1)    // buffer cur^1 was last read before the previous barrier
+    for (int it_ = 0; it_ < niter; ++it_) {
+      const int idx = it_ * NG + grp;
+      if (idx + NG < total) KV_DMA(idx + NG, cur ^ 1)  // buffer cur^1 was last read before the previous barrier
+      if (NG == 1 || idx < total) {
       const char* Qs = smem + cur * (2 * TILE_BYTES + 512); const char* Ds = Qs + TILE_BYTES;
       const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * TILE_BYTES); const float* del_s = lse_s + 64;
       const int ti = idx % ntile;
@@ -586,11 +593,32 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_kernel(AttnParams p) {
           }
         }
       }
+      }
       __syncthreads();
       cur ^= 1;
     }
   }
 #undef KV_DMA
+  if (NG == 2) {
+    // group 1 hands its partial sums to group 0 through LDS, 32 accumulators (one d-block of dK and dV) at a time
+    float* red = reinterpret_cast<float*>(smem_all);
+#pragma unroll
+    for (int b = 0; b < KB; ++b)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        if (grp == 1) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) { red[g * 256 + tid] = DK[b][db][g]; red[(16 + g) * 256 + tid] = DV[b][db][g]; }
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) { DK[b][db][g] += red[g * 256 + tid]; DV[b][db][g] += red[(16 + g) * 256 + tid]; }
+        }
+        __syncthreads();
+      }
+    if (grp == 1) return;
+  }
 #pragma unroll
   for (int b = 0; b < KB; ++b) {
     const int kloc = wave * 32 * KB + 32 * b + r;
@@ -716,16 +744,18 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();   // drop a stale error of an earlier, unrelated runtime call
   if ((which & 3) == 0) return DTA_EINVAL;
+  // NG = 2 (two wave groups, two waves per SIMD) was measured at 0.52x the speed of NG = 1 on the tau2 trie: 128
+  // accumulators + 64 K/V fragment registers do not fit 256 registers per wave (69 spills).  Not instantiated.
   const int ndkv = dkv_units ? n_units : nkt;
   const bool pair = p.group % 2 == 0;
   const dim3 gq(pair ? nqt * Hq / 2 : nqt * Hq), bq(pair ? 512 : 256);
   if (dtype == DTA_BF16) {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 1>), gq, bq, 0, st, p); }
-    if (which & 2) { hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_BF16, DTA_KTILE / 128>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
+    if (which & 2) { hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_BF16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
                      if (dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_BF16>, dim3(n_splits * Hkv), dim3(256), 0, st, p); }
   } else {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 1>), gq, bq, 0, st, p); }
-    if (which & 2) { hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_F16, DTA_KTILE / 128>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
+    if (which & 2) { hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_F16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
                      if (dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_F16>, dim3(n_splits * Hkv), dim3(256), 0, st, p); }
   }
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
