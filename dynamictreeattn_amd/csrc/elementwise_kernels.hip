@@ -27,7 +27,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // RMSNorm over rows of H (H % 8 == 0, H <= 8192).  One wave per row, 4 rows per workgroup, grid-stride.
 // ---------------------------------------------------------------------------------------------
 template <int DT>
-__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_, void* __restrict__ y_,
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* __restrict__ x_, const void* __restrict__ delta_, const void* __restrict__ w_,
+                                                          void* __restrict__ xout_, void* __restrict__ y_,
                                                           float* __restrict__ rstd, int R, int H, float eps) {
   using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -37,10 +38,24 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* __restrict
     const e* x = reinterpret_cast<const e*>(x_) + (int64_t)row * H;
     e* y = reinterpret_cast<e*>(y_) + (int64_t)row * H;
     float ss = 0.f;
-    for (int i = lane; i < nv; i += 64) {
-      const v8 v = *reinterpret_cast<const v8*>(x + 8 * i);
+    if (delta_) {                                      // residual stream update fused in: x_out = x + delta (rounded), then normalised
+      const e* dl = reinterpret_cast<const e*>(delta_) + (int64_t)row * H;
+      e* xo = reinterpret_cast<e*>(xout_) + (int64_t)row * H;
+      for (int i = lane; i < nv; i += 64) {
+        const v8 v = *reinterpret_cast<const v8*>(x + 8 * i); const v8 d = *reinterpret_cast<const v8*>(dl + 8 * i);
+        v8 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; ss = __builtin_fmaf(f, f, ss); }
+        for (int j = 0; j < 8; ++j) { o[j] = (e)((float)v[j] + (float)d[j]); const float f = (float)o[j]; ss = __builtin_fmaf(f, f, ss); }
+        *reinterpret_cast<v8*>(xo + 8 * i) = o;
+      }
+      x = xo;                                          // second pass re-reads the wave's own (L1/L2-hot) row
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    } else {
+      for (int i = lane; i < nv; i += 64) {
+        const v8 v = *reinterpret_cast<const v8*>(x + 8 * i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; ss = __builtin_fmaf(f, f, ss); }
+      }
     }
     ss = wave_sum(ss);
     const float r = __builtin_amdgcn_rsqf(ss / (float)H + eps);
@@ -59,6 +74,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* __restrict
 // dx = r·(dt − t̂·mean(dt·t̂)), dt = dy·w, t̂ = x·r ;  dw partial per workgroup: Σ_rows dy·t̂  (H <= 4096 -> <= 8 x v8 per lane)
 template <int DT>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_, const void* __restrict__ dy_,
+                                                          const void* __restrict__ dres_,
                                                           const float* __restrict__ rstd, void* __restrict__ dx_, float* __restrict__ dw_part,
                                                           int R, int H) {
   using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
@@ -96,8 +112,14 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict
         const v8 v = *reinterpret_cast<const v8*>(x + 8 * i); const v8 g = *reinterpret_cast<const v8*>(dy + 8 * i);
         const v8 wv = *reinterpret_cast<const v8*>(w + 8 * i);
         v8 o;
+        if (dres_) {                                   // gradient arriving on the residual stream is added here (one pass less)
+          const v8 dr = *reinterpret_cast<const v8*>(reinterpret_cast<const e*>(dres_) + (int64_t)row * H + 8 * i);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float t = (float)v[j] * r; o[j] = (e)(r * ((float)g[j] * (float)wv[j] - t * dot)); }
+          for (int j = 0; j < 8; ++j) { const float t = (float)v[j] * r; o[j] = (e)(r * ((float)g[j] * (float)wv[j] - t * dot) + (float)dr[j]); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float t = (float)v[j] * r; o[j] = (e)(r * ((float)g[j] * (float)wv[j] - t * dot)); }
+        }
         *reinterpret_cast<v8*>(dx + 8 * i) = o;
       }
     }
@@ -277,21 +299,22 @@ inline int row_blocks(int64_t rows, int per_block, int cap) { int64_t b = (rows 
        else hipLaunchKernelGGL(KERNEL<DTA_F16>, dim3(GRID), dim3(256), 0, st_, __VA_ARGS__);               \
        return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH; } while (0)
 
-extern "C" int dta_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int32_t R, int32_t H, float eps, int32_t dtype, void* stream) {
-  if (!x || !w || !y || !rstd || R <= 0 || H <= 0) return DTA_EINVAL;
+extern "C" int dta_rmsnorm_fwd(const void* x, const void* delta, const void* w, void* x_out, void* y, float* rstd,
+                               int32_t R, int32_t H, float eps, int32_t dtype, void* stream) {
+  if (!x || !w || !y || !rstd || R <= 0 || H <= 0 || ((delta != nullptr) != (x_out != nullptr))) return DTA_EINVAL;
   if ((dtype != DTA_BF16 && dtype != DTA_F16) || H % 8 || H > 4096) return DTA_EUNSUPPORTED;
-  if (!al16(x) || !al16(w) || !al16(y)) return DTA_EALIGN;
-  DTA_DISPATCH(rmsnorm_fwd_kernel, row_blocks(R, 4, 4096), x, w, y, rstd, R, H, eps);
+  if (!al16(x) || !al16(w) || !al16(y) || (delta && (!al16(delta) || !al16(x_out)))) return DTA_EALIGN;
+  DTA_DISPATCH(rmsnorm_fwd_kernel, row_blocks(R, 4, 4096), x, delta, w, x_out, y, rstd, R, H, eps);
 }
 
 /* dw_partial: float [dta_rmsnorm_bwd_blocks(R), H]; the caller sums it over dim 0. */
 extern "C" int dta_rmsnorm_bwd_blocks(int32_t R) { return row_blocks(R, 4, 512); }
-extern "C" int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rstd, void* dx, float* dw_partial,
+extern "C" int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dres, const float* rstd, void* dx, float* dw_partial,
                                int32_t R, int32_t H, int32_t dtype, void* stream) {
   if (!x || !w || !dy || !rstd || !dx || !dw_partial || R <= 0 || H <= 0) return DTA_EINVAL;
   if ((dtype != DTA_BF16 && dtype != DTA_F16) || H % 8 || H > 4096) return DTA_EUNSUPPORTED;
-  if (!al16(x) || !al16(w) || !al16(dy) || !al16(dx)) return DTA_EALIGN;
-  DTA_DISPATCH(rmsnorm_bwd_kernel, row_blocks(R, 4, 512), x, w, dy, rstd, dx, dw_partial, R, H);
+  if (!al16(x) || !al16(w) || !al16(dy) || !al16(dx) || (dres && !al16(dres))) return DTA_EALIGN;
+  DTA_DISPATCH(rmsnorm_bwd_kernel, row_blocks(R, 4, 512), x, w, dy, dres, rstd, dx, dw_partial, R, H);
 }
 
 extern "C" int dta_qk_norm_rope_fwd(const void* x, const void* w, const float* cos_sin, void* y, float* rstd,

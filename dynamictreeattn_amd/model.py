@@ -111,17 +111,18 @@ def _cfg_of(model):
     return c.num_attention_heads, c.num_key_value_heads, D, float(getattr(c, "rms_norm_eps", 1e-6)), float(theta)
 
 
-def _layer_forward(layer, x, cos_sin, meta, Hq, Hkv, D, eps):
-    """One decoder layer over the packed rows: hipBLASLt GEMMs through torch; everything between them
-    is a HIP kernel of this package (ops.rms_norm, ops.qk_norm_rope, ops.tree_attention, ops.swiglu)."""
-    T = x.shape[0]
+def _layer_forward(layer, res, delta, cos_sin, meta, Hq, Hkv, D, eps):
+    """One decoder layer over the packed rows.  The hidden state enters as (residual stream, pending update)
+    so that each residual add is fused into the RMSNorm that follows it.  hipBLASLt GEMMs through torch;
+    everything between them is a HIP kernel of this package."""
+    T = res.shape[0]
     a = layer.self_attn
-    h = ops.rms_norm(x, layer.input_layernorm.weight, eps)
+    res, h = ops.add_rms_norm(res, delta, layer.input_layernorm.weight, eps)
     bq, bk, bv = (getattr(m_, "bias", None) for m_ in (a.q_proj, a.k_proj, a.v_proj))
     if FUSE_PROJECTIONS:
         # one projection GEMM for q,k,v (and one for gate,up below): the weights stay separate parameters with
-        # their HF names; the concatenation is an 8 MB copy whose backward hands each its gradient slice
-        qkv = F.linear(h, torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0),
+        # their HF names; stacking them is three plain copies whose backward hands out gradient row slices
+        qkv = F.linear(h, ops.stack_rows(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight),
                        torch.cat([bq, bk, bv]) if bq is not None else None).view(T, Hq + 2 * Hkv, D)
         q, k, v = qkv.split([Hq, Hkv, Hkv], dim=1)            # split's backward is ONE concatenation
     else:
@@ -132,15 +133,14 @@ def _layer_forward(layer, x, cos_sin, meta, Hq, Hkv, D, eps):
     q = ops.qk_norm_rope(q, qn.weight if qn is not None else None, cos_sin, eps)
     k = ops.qk_norm_rope(k, kn.weight if kn is not None else None, cos_sin, eps)
     o = ops.tree_attention(q, k, v, meta)
-    x = x + F.linear(o.reshape(T, Hq * D), a.o_proj.weight)
-    h = ops.rms_norm(x, layer.post_attention_layernorm.weight, eps)
+    attn_out = F.linear(o.reshape(T, Hq * D), a.o_proj.weight)
+    res, h = ops.add_rms_norm(res, attn_out, layer.post_attention_layernorm.weight, eps)
     m = layer.mlp
     if FUSE_PROJECTIONS:
-        act = ops.swiglu_fused(F.linear(h, torch.cat([m.gate_proj.weight, m.up_proj.weight], dim=0)))
+        act = ops.swiglu_fused(F.linear(h, ops.stack_rows(m.gate_proj.weight, m.up_proj.weight)))
     else:
         act = ops.swiglu(F.linear(h, m.gate_proj.weight), F.linear(h, m.up_proj.weight))
-    x = x + F.linear(act, m.down_proj.weight)
-    return x
+    return res, F.linear(act, m.down_proj.weight)
 
 
 def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta, checkpoint_layers: bool = False) -> torch.Tensor:
@@ -148,15 +148,15 @@ def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta,
     Qwen2/Qwen3 *ForCausalLM (duck-typed)."""
     Hq, Hkv, D, eps, theta = _cfg_of(model)
     body = model.model
-    x = F.embedding(tokens, body.embed_tokens.weight)
+    res, delta = F.embedding(tokens, body.embed_tokens.weight), None
     cos_sin = ops.rope_cos_sin(depth, D, theta)
     for layer in body.layers:
         if checkpoint_layers and torch.is_grad_enabled():
             from torch.utils.checkpoint import checkpoint
-            x = checkpoint(_layer_forward, layer, x, cos_sin, meta, Hq, Hkv, D, eps, use_reentrant=False)
+            res, delta = checkpoint(_layer_forward, layer, res, delta, cos_sin, meta, Hq, Hkv, D, eps, use_reentrant=False)
         else:
-            x = _layer_forward(layer, x, cos_sin, meta, Hq, Hkv, D, eps)
-    return ops.rms_norm(x, body.norm.weight, eps)
+            res, delta = _layer_forward(layer, res, delta, cos_sin, meta, Hq, Hkv, D, eps)
+    return ops.add_rms_norm(res, delta, body.norm.weight, eps)[1]
 
 
 def head_weight(model) -> torch.Tensor:

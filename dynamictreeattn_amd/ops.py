@@ -270,30 +270,46 @@ def lm_head_rows(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy,
 # Fused decoder-layer row kernels (RMSNorm, head-norm + RoPE, SwiGLU)
 # --------------------------------------------------------------------------------------------------
 class _RMSNorm(torch.autograd.Function):
+    """(x_out, y) = (x + delta, rmsnorm(x + delta) * w); delta may be None (then x_out is x itself)."""
+
     @staticmethod
-    def forward(ctx, x, w, eps):
+    def forward(ctx, x, delta, w, eps):
         _require_cuda(x, w)
         x2 = x.contiguous().view(-1, x.shape[-1])
         R, H = x2.shape
         y = torch.empty_like(x2)
         rstd = torch.empty(R, dtype=torch.float32, device=x.device)
-        check(lib().dta_rmsnorm_fwd(ptr(x2), ptr(w), ptr(y), ptr(rstd), R, H, float(eps), _DT[x.dtype], _stream()), "dta_rmsnorm_fwd")
-        ctx.save_for_backward(x2, w, rstd)
-        return y.view(x.shape)
+        if delta is not None:
+            d2 = delta.contiguous().view(R, H)
+            xo = torch.empty_like(x2)
+        else:
+            d2, xo = None, None
+        check(lib().dta_rmsnorm_fwd(ptr(x2), ptr(d2), ptr(w), ptr(xo), ptr(y), ptr(rstd), R, H, float(eps), _DT[x.dtype], _stream()), "dta_rmsnorm_fwd")
+        xin = xo if xo is not None else x2
+        ctx.save_for_backward(xin, w, rstd)
+        ctx.has_delta = delta is not None
+        return xin.view(x.shape), y.view(x.shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, g_res, dy):
         x2, w, rstd = ctx.saved_tensors
         R, H = x2.shape
         dy2 = dy.contiguous().view(R, H)
+        gr = g_res.contiguous().view(R, H) if g_res is not None else None
         dx = torch.empty_like(x2)
         part = torch.empty(lib().dta_rmsnorm_bwd_blocks(R), H, dtype=torch.float32, device=x2.device)
-        check(lib().dta_rmsnorm_bwd(ptr(x2), ptr(w), ptr(dy2), ptr(rstd), ptr(dx), ptr(part), R, H, _DT[x2.dtype], _stream()), "dta_rmsnorm_bwd")
-        return dx.view(dy.shape), part.sum(0).to(w.dtype), None
+        check(lib().dta_rmsnorm_bwd(ptr(x2), ptr(w), ptr(dy2), ptr(gr), ptr(rstd), ptr(dx), ptr(part), R, H, _DT[x2.dtype], _stream()), "dta_rmsnorm_bwd")
+        dx = dx.view(dy.shape)
+        return dx, (dx if ctx.has_delta else None), part.sum(0).to(w.dtype), None
 
 
 def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
-    return _RMSNorm.apply(x, w, eps)
+    return _RMSNorm.apply(x, None, w, eps)[1]
+
+
+def add_rms_norm(x: torch.Tensor, delta: Optional[torch.Tensor], w: torch.Tensor, eps: float):
+    """Residual-stream update fused with the following RMSNorm: returns (x + delta, rmsnorm(x + delta) * w)."""
+    return _RMSNorm.apply(x, delta, w, eps)
 
 
 class _QKNormRope(torch.autograd.Function):
@@ -382,3 +398,30 @@ def swiglu(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
 def swiglu_fused(gu: torch.Tensor) -> torch.Tensor:
     """gu [rows, 2C] = (gate | up) of one fused projection GEMM -> silu(gate) * up  [rows, C]."""
     return _SwiGLU.apply(gu, None, None)
+
+
+class _StackRows(torch.autograd.Function):
+    """Concatenate weight matrices along dim 0 into one GEMM operand.  Backward hands each input its row
+    slice of the fused gradient as a VIEW (no copy); forward is len(ws) plain copies (torch.cat's batched
+    copy kernel took 170 us for two 6 MB inputs on gfx950)."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        rows = [w.shape[0] for w in ws]
+        out = torch.empty((sum(rows),) + tuple(ws[0].shape[1:]), dtype=ws[0].dtype, device=ws[0].device)
+        o = 0
+        for w, r in zip(ws, rows):
+            out[o:o + r].copy_(w); o += r
+        ctx.rows = rows
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for r in ctx.rows:
+            outs.append(g[o:o + r]); o += r
+        return tuple(outs)
+
+
+def stack_rows(*ws: torch.Tensor) -> torch.Tensor:
+    return _StackRows.apply(*ws)

@@ -157,9 +157,13 @@ int dta_logprob_entropy_bwd(void* logits_inout, const int64_t* labels, const flo
  * 248-252, 351-353): RMSNorm = w * cast(x * rsqrt(mean(x^2)+eps)); rotate-half RoPE at position =
  * trie depth; SwiGLU = cast(silu(g)) * u.
  * ------------------------------------------------------------------------------------------- */
-int dta_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int32_t R, int32_t H, float eps, int32_t dtype, void* stream);
+/* delta/x_out both NULL: y = norm(x).  Both given: x_out = x + delta (the residual-stream update of the decoder
+ * layer, rounded to the storage dtype) and y = norm(x_out), in one pass.  bwd: `x` is the normalised input
+ * (x_out of the forward), `dres` (may be NULL) the gradient arriving on the residual stream, added to dx. */
+int dta_rmsnorm_fwd(const void* x, const void* delta, const void* w, void* x_out, void* y, float* rstd,
+                    int32_t R, int32_t H, float eps, int32_t dtype, void* stream);
 int dta_rmsnorm_bwd_blocks(int32_t R);   /* rows of the dw_partial workspace [blocks, H] (float); caller sums dim 0 */
-int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rstd, void* dx, float* dw_partial,
+int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dres, const float* rstd, void* dx, float* dw_partial,
                     int32_t R, int32_t H, int32_t dtype, void* stream);
 /* x: [T, NH, 128] with token stride x_stride_t; cos_sin: float [T, 128] = {cos[64], sin[64]} of the token's
  * depth; y: [T, NH, 128] contiguous; w (head-norm weight [128]) may be NULL = RoPE only. */

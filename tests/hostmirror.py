@@ -70,6 +70,12 @@ def _cpu_rms_norm(x, w, eps):
     return w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype)
 
 
+def _cpu_add_rms_norm(x, delta, w, eps):
+    if delta is not None:
+        x = x + delta
+    return x, _cpu_rms_norm(x, w, eps)
+
+
 def _cpu_qk_norm_rope(x, w, cos_sin, eps):
     if w is not None:
         x = _cpu_rms_norm(x, w, eps)
@@ -95,6 +101,7 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "tree_attention", _cpu_attention)
     monkeypatch.setattr(ops, "lm_head_rows", _cpu_lm_head_rows)
     monkeypatch.setattr(ops, "rms_norm", _cpu_rms_norm)
+    monkeypatch.setattr(ops, "add_rms_norm", _cpu_add_rms_norm)
     monkeypatch.setattr(ops, "qk_norm_rope", _cpu_qk_norm_rope)
     monkeypatch.setattr(ops, "swiglu", _cpu_swiglu)
     monkeypatch.setattr(ops, "swiglu_fused", _cpu_swiglu_fused)

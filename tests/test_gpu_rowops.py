@@ -36,6 +36,11 @@ def test_rmsnorm(R, H, dtype):
     g = torch.Generator().manual_seed(R + H)
     x = torch.randn(R, H, generator=g) * 2; w = (1 + 0.2 * torch.randn(H, generator=g)).to(dtype)
     _pair(lambda a, b: ops.rms_norm(a, b, 1e-6), lambda a, b: hostmirror._cpu_rms_norm(a, b, 1e-6), [x, w], dtype)
+    # residual add fused in; both outputs carry gradient (the residual stream continues past the norm)
+    d = torch.randn(R, H, generator=g)
+    def both(fn):
+        return lambda a, dl, b: (lambda xo, y: y + 0.5 * xo)(*fn(a, dl, b, 1e-6))
+    _pair(both(ops.add_rms_norm), both(hostmirror._cpu_add_rms_norm), [x, d, w], dtype)
 
 
 @pytest.mark.parametrize("T,NH,norm,dtype", [(1, 1, True, torch.bfloat16), (33, 16, True, torch.bfloat16), (257, 8, True, torch.float16), (50, 3, False, torch.bfloat16)])
