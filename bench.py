@@ -30,6 +30,7 @@ from dynamictreeattn_amd.model import Qwen3TreeLM, make_config
 from dynamictreeattn_amd.token_trie import TokenTrie
 from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine
 
+MODEL_NAME = {"qwen3-0.6b": "Qwen3-0.6B", "qwen3-4b": "Qwen3-4B"}
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16 peak, MI355X_MICROARCH.md "Chip-level parameters"
 ATTACH = {"w_logprobs": -1.0, "w_entropy": 0.1}      # run_all.py:11-14
 
@@ -217,11 +218,11 @@ def main():
         pass
 
     out = {
-        "metric": "tree-attn fwd+bwd tokens/sec, Qwen3-0.6B tau2-16k tries", "value": n_tokens / wall, "unit": "tokens/s",
+        "metric": f"tree-attn fwd+bwd tokens/sec, {MODEL_NAME[args.model]} tau2-16k tries", "value": n_tokens / wall, "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "tau2-16k-shaped trie batch (8 rollouts x 6 turns, 2000-token shared prompt, 48 seqs ~180k tokens "
-                               "per call), one call per GPU per step, Qwen3-0.6B random-init bf16, tree fwd+bwd, block_size 2048, permute=ours",
+                               f"per call), one call per GPU per step, {MODEL_NAME[args.model]} random-init bf16, tree fwd+bwd, block_size {args.block_size}, permute=ours",
                    "calls_per_step": world, "balancer": "LB_by_DFS_and_TM" if world > 1 else "none",
                    "grad_allreduce": "RCCL sum" if world > 1 else "none"},
         "tree_tokens_per_s": n_tree / wall,

@@ -143,14 +143,56 @@ constexpr int QK_LDS = 2 * (2 * TILE_BYTES + SE_BYTES);            // double-buf
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
+// Per-lane byte offsets of every fragment read inside one image, computed once: the XOR swizzle depends on the
+// lane only (row blocks of 32 and k-steps of 16 rows leave row&3 and (row>>2)&3 unchanged), so inside the tile
+// loop every ds_read is <lane offset register> + <compile-time immediate>.
+struct FragOffs { int row[8]; int tr[8]; };
+__device__ __forceinline__ FragOffs frag_offsets(int lane) {
+  FragOffs o;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) o.row[s] = img_off(r, 2 * s + h);
+  const int G = lane >> 4, i = lane & 15, qd = i >> 2, pp = i & 3;
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int ch = 4 * mb + 2 * (G & 1) + (pp >> 1);
+    o.tr[mb] = img_off(4 * h + qd, ch) + 8 * (pp & 1);
+    o.tr[4 + mb] = img_off(4 * h + qd + 8, ch) + 8 * (pp & 1);
+  }
+  return o;
+}
+template <class V8> __device__ __forceinline__ V8 tr_frag_o(const char* img_r0, const FragOffs& o, int mb) {
+  s16x4 lo = tr_read(img_r0 + o.tr[mb]);
+  s16x4 hi = tr_read(img_r0 + o.tr[4 + mb]);
+  s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(V8, both);
+}
+
+// K/V tile pair global -> LDS by LDS-DMA: NW waves move the 16 + 16 one-KiB pieces (4 image rows each) of the
+// two 64-row images; the image's XOR swizzle goes on the per-lane SOURCE chunk.  subtree_end of the 64 keys
+// takes the ordinary path first (an ordinary load issued behind a DMA would drain it).
+#define DTA_KV_DMA(BASE, K0, KEND, NW)                                                                     \
+  { char* base_ = (BASE);                                                                                  \
+    if (tid < 64) { const int ki_ = (K0) + tid;                                                            \
+      reinterpret_cast<int*>(base_ + 2 * TILE_BYTES)[tid] = (ki_ < (KEND)) ? (p.subtree_end ? p.subtree_end[ki_] : 0x7fffffff) : 0; } \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) {                                             \
+      const int piece_ = wave * (16 / (NW)) + i_, row_ = 4 * piece_ + (lane >> 4);                         \
+      const int ch_ = (lane & 15) ^ (((row_ & 3) << 2) | ((row_ >> 2) & 3));                                \
+      int kr_ = (K0) + row_; kr_ = kr_ < p.Tk ? kr_ : p.Tk - 1;                                            \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (int64_t)kr_ * p.kv_st + ch_ * 8), \
+                                       (__attribute__((address_space(3))) void*)(base_ + piece_ * 1024), 16, 0, 0);               \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (int64_t)kr_ * p.v_st + ch_ * 8),  \
+                                       (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + piece_ * 1024), 16, 0, 0); } }
+
 // =================================================================================================
 // forward.  HPB = query heads of one kv group handled by a workgroup (waves 4*hb .. 4*hb+3 own head hb);
-// they share the staged K/V tiles.  One barrier per 64-key tile, LDS double buffered.
+// they share the staged K/V tiles.  One barrier per 64-key tile, LDS double buffered, tile loop unrolled
+// over the two buffers so that every LDS address is lane-offset + immediate.
 // =================================================================================================
 template <int DT, int HPB>
 __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams p) {
   using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
-  constexpr int NT = 256 * HPB, CPT = 1024 / NT;
+  constexpr int NW = 4 * HPB, BUF = 2 * TILE_BYTES + SE_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[QK_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -177,14 +219,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
 
   const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
   const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.v_sh;
-  u32x4 kreg[CPT], vreg[CPT]; int sereg = 0;
-#define FWD_LOAD(K0, KEND)                                                                                 \
-  { DTA_STAGE_LOAD(kreg, vreg, kbase, vbase, p.kv_st, p.v_st, (K0), p.Tk, NT, CPT)                        \
-    if (tid < 64) { const int ki_ = (K0) + tid; sereg = (ki_ < (KEND)) ? (p.subtree_end ? p.subtree_end[ki_] : 0x7fffffff) : 0; } }
-#define FWD_WRITE(B)                                                                                       \
-  { char* base_ = smem + (B) * (2 * TILE_BYTES + SE_BYTES);                                                \
-    DTA_STAGE_WRITE(kreg, vreg, base_, base_ + TILE_BYTES, NT, CPT)                                        \
-    if (tid < 64) reinterpret_cast<int*>(base_ + 2 * TILE_BYTES)[tid] = sereg; }
+  const FragOffs offs = frag_offsets(lane);
 
   f32x16 O[4];
 #pragma unroll
@@ -195,81 +230,64 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
   const float c = p.scale * LOG2E;
 
   int ck0 = it.k0; bool cmask = it.masked();
-  FWD_LOAD(it.k0, it.kend) FWD_WRITE(0)
+  DTA_KV_DMA(smem, it.k0, it.kend, NW)
   bool has_next = it.advance();
-  int nk0 = it.k0; bool nmask = has_next ? it.masked() : false;
-  if (has_next) FWD_LOAD(it.k0, it.kend)
-  __syncthreads();
-  int cur = 0;
-  while (true) {
-    bool has_next2 = false;
-    if (has_next) {
-      FWD_WRITE(cur ^ 1)
-      has_next2 = it.advance();
-      if (has_next2) FWD_LOAD(it.k0, it.kend)
-    }
-    const char* Ks = smem + cur * (2 * TILE_BYTES + SE_BYTES); const char* Vs = Ks + TILE_BYTES;
-    const int* se_s = reinterpret_cast<const int*>(Ks + 2 * TILE_BYTES);
-    // ---- S^T[key][q] = K · Q^T -----------------------------------------------------------------
-    f32x16 X[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int g = 0; g < 16; ++g) X[kb][g] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) X[kb] = T::mma(row_frag<v8>(Ks, 32 * kb + r, 2 * s + h), qf[s], X[kb]);
-    }
-    if (cmask) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int kl = 32 * kb + 8 * gq + 4 * h;
-          const int4 se4 = *reinterpret_cast<const int4*>(se_s + kl);
-          const int sev[4] = {se4.x, se4.y, se4.z, se4.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const bool ok = (ck0 + kl + j <= qidx) && (qidx < sev[j]);
-            X[kb][4 * gq + j] = ok ? X[kb][4 * gq + j] : -INFINITY;
-          }
-        }
-    }
-    // ---- online softmax, log2 domain; O is rescaled only when some row's maximum really grew -------
-    float mx = max3(X[0][0], X[0][1], X[0][2]);
-#pragma unroll
-    for (int g = 3; g < 15; g += 2) mx = max3(mx, X[0][g], X[0][g + 1]);
-    mx = fmaxf(mx, X[0][15]);
-#pragma unroll
-    for (int g = 0; g < 16; g += 2) mx = max3(mx, X[1][g], X[1][g + 1]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mc = mx * c;
-    if (__any(mc > m)) {
-      const float mnew = fmaxf(m, mc);
-      const float alpha = fast_exp2(m - mnew);
-      m = mnew; lsum *= alpha;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) O[db][g] *= alpha;
-    }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) { const float pv = fast_exp2(__builtin_fmaf(X[kb][g], c, -m)); lsum += pv; X[kb][g] = pv; }
-    // ---- O^T[d][q] += V^T · P^T ------------------------------------------------------------------
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const v8 pb = pack_half<DT>(X[s4 >> 1], s4 & 1);
-#pragma unroll
-      for (int db = 0; db < 4; ++db) O[db] = T::mma(tr_frag<v8>(Vs, 16 * s4, db, lane), pb, O[db]);
-    }
-    __syncthreads();
-    if (!has_next) break;
-    cur ^= 1; ck0 = nk0; cmask = nmask;
-    has_next = has_next2; nk0 = it.k0; nmask = has_next2 ? it.masked() : false;
+  __syncthreads();                                                 // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+
+  // one tile out of buffer BUFI (compile-time): prefetch the next tile into the other buffer, S^T, softmax, PV
+#define FWD_TILE(BUFI)                                                                                     \
+  {                                                                                                        \
+    int nk0_ = 0; bool nmask_ = false;                                                                     \
+    if (has_next) { nk0_ = it.k0; nmask_ = it.masked(); DTA_KV_DMA(smem + (1 - (BUFI)) * BUF, it.k0, it.kend, NW) } \
+    const char* Ks = smem + (BUFI) * BUF; const char* Vs = Ks + TILE_BYTES;                                \
+    const int* se_s = reinterpret_cast<const int*>(Ks + 2 * TILE_BYTES);                                   \
+    f32x16 X[2];                                                                                           \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                     \
+      _Pragma("unroll") for (int g = 0; g < 16; ++g) X[kb][g] = 0.f;                                       \
+      _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                        \
+        X[kb] = T::mma(*reinterpret_cast<const v8*>(Ks + 8192 * kb + offs.row[s]), qf[s], X[kb]);          \
+    }                                                                                                      \
+    if (cmask) {                                                                                           \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                     \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                 \
+          const int kl = 32 * kb + 8 * gq + 4 * h;                                                         \
+          const int4 se4 = *reinterpret_cast<const int4*>(se_s + kl);                                      \
+          const int sev[4] = {se4.x, se4.y, se4.z, se4.w};                                                 \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+            const bool ok = (ck0 + kl + j <= qidx) && (qidx < sev[j]);                                     \
+            X[kb][4 * gq + j] = ok ? X[kb][4 * gq + j] : -INFINITY;                                        \
+          }                                                                                                \
+        }                                                                                                  \
+    }                                                                                                      \
+    float mx = max3(X[0][0], X[0][1], X[0][2]);                                                            \
+    _Pragma("unroll") for (int g = 3; g < 15; g += 2) mx = max3(mx, X[0][g], X[0][g + 1]);                 \
+    mx = fmaxf(mx, X[0][15]);                                                                              \
+    _Pragma("unroll") for (int g = 0; g < 16; g += 2) mx = max3(mx, X[1][g], X[1][g + 1]);                 \
+    mx = fmaxf(mx, __shfl_xor(mx, 32));                                                                    \
+    const float mc = mx * c;                                                                               \
+    if (__any(mc > m)) {                       /* O is rescaled only when some row's maximum really grew */ \
+      const float mnew = fmaxf(m, mc);                                                                     \
+      const float alpha = fast_exp2(m - mnew);                                                             \
+      m = mnew; lsum *= alpha;                                                                             \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db)                                                     \
+        _Pragma("unroll") for (int g = 0; g < 16; ++g) O[db][g] *= alpha;                                  \
+    }                                                                                                      \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                       \
+      _Pragma("unroll") for (int g = 0; g < 16; ++g) { const float pv = fast_exp2(__builtin_fmaf(X[kb][g], c, -m)); lsum += pv; X[kb][g] = pv; } \
+    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                     \
+      const v8 pb = pack_half<DT>(X[s4 >> 1], s4 & 1);                                                     \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) O[db] = T::mma(tr_frag_o<v8>(Vs + 4096 * s4, offs, db), pb, O[db]); \
+    }                                                                                                      \
+    __syncthreads();                                                                                       \
+    if (!has_next) break;                                                                                  \
+    ck0 = nk0_; cmask = nmask_;                                                                            \
+    has_next = it.advance();                                                                               \
   }
-#undef FWD_LOAD
-#undef FWD_WRITE
+  while (true) {
+    FWD_TILE(0)
+    FWD_TILE(1)
+  }
+#undef FWD_TILE
 
   lsum += __shfl_xor(lsum, 32);
   const float inv = 1.f / lsum;
