@@ -143,6 +143,16 @@ constexpr int QK_LDS = 2 * (2 * TILE_BYTES + SE_BYTES);            // double-buf
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
+// Diagnostic ablation switches (-DDTA_ABL=bits; product builds leave them off): 1 = no exp, 2 = no K row reads,
+// 4 = no V transposed reads.  They only exist to attribute time (cdna guide, rule 17); results are wrong when set.
+#ifndef DTA_ABL
+#define DTA_ABL 0
+#endif
+#define DTA_ABL_E(real, fake) ((DTA_ABL & 1) ? (fake) : (real))
+#define DTA_ABL_A(real, fake) ((DTA_ABL & 2) ? (fake) : (real))
+#define DTA_ABL_B(real, fake) ((DTA_ABL & 4) ? (fake) : (real))
+// 8 = no per-tile barrier in the forward (races: timing only)
+
 // Per-lane byte offsets of every fragment read inside one image, computed once: the XOR swizzle depends on the
 // lane only (row blocks of 32 and k-steps of 16 rows leave row&3 and (row>>2)&3 unchanged), so inside the tile
 // loop every ds_read is <lane offset register> + <compile-time immediate>.
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                     \
       _Pragma("unroll") for (int g = 0; g < 16; ++g) X[kb][g] = 0.f;                                       \
       _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                        \
-        X[kb] = T::mma(*reinterpret_cast<const v8*>(Ks + 8192 * kb + offs.row[s]), qf[s], X[kb]);          \
+        X[kb] = T::mma(DTA_ABL_A(*reinterpret_cast<const v8*>(Ks + 8192 * kb + offs.row[s]), qf[(s + 1) & 7]), qf[s], X[kb]); \
     }                                                                                                      \
     if (cmask) {                                                                                           \
       _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                     \
@@ -273,12 +283,12 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
         _Pragma("unroll") for (int g = 0; g < 16; ++g) O[db][g] *= alpha;                                  \
     }                                                                                                      \
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                       \
-      _Pragma("unroll") for (int g = 0; g < 16; ++g) { const float pv = fast_exp2(__builtin_fmaf(X[kb][g], c, -m)); lsum += pv; X[kb][g] = pv; } \
+      _Pragma("unroll") for (int g = 0; g < 16; ++g) { const float pv = DTA_ABL_E(fast_exp2(__builtin_fmaf(X[kb][g], c, -m)), X[kb][g] * c); lsum += pv; X[kb][g] = pv; } \
     _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                     \
       const v8 pb = pack_half<DT>(X[s4 >> 1], s4 & 1);                                                     \
-      _Pragma("unroll") for (int db = 0; db < 4; ++db) O[db] = T::mma(tr_frag_o<v8>(Vs + 4096 * s4, offs, db), pb, O[db]); \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) O[db] = T::mma(DTA_ABL_B(tr_frag_o<v8>(Vs + 4096 * s4, offs, db), qf[db + s4]), pb, O[db]); \
     }                                                                                                      \
-    __syncthreads();                                                                                       \
+    if (!(DTA_ABL & 8)) __syncthreads();                                                                   \
     if (!has_next) break;                                                                                  \
     ck0 = nk0_; cmask = nmask_;                                                                            \
     has_next = it.advance();                                                                               \
