@@ -201,7 +201,7 @@ def main():
     dkv_tf, dkv_ms = tf(8, "bwd_dkv")
     dq_tf, dq_ms = tf(2, "bwd_dq")
     fwd_tf, fwd_ms = tf(4, "fwd")
-    attn_ms_total = ms["fwd"][0] + ms["bwd_dq"][0] + ms["bwd_dkv"][0]
+    attn_ms_total = ms["fwd"][0] + ms["bwd_dq"][0] + ms["bwd_dkv"][0] + ms["bwd_dkv_finalize"][0]
     all_tf = (14 * Hq * D * pairs * L) / (attn_ms_total * 1e-3) / 1e12 if attn_ms_total > 0 else 0.0
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; take the latest
@@ -231,6 +231,7 @@ def main():
                      "flops_per_pair_per_layer": 8 * Hq * D, "pairs_per_step": pairs / max(args.steps, 1),
                      "other_kernels": {"tree_attn_fwd_kernel": {"achieved": fwd_tf, "avg_launch_ms": fwd_ms, "flops_per_pair_per_layer": 4 * Hq * D},
                                        "tree_attn_bwd_dq_kernel": {"achieved": dq_tf, "avg_launch_ms": dq_ms, "flops_per_pair_per_layer": 2 * Hq * D},
+                                       "tree_attn_bwd_dkv_finalize_kernel": {"avg_launch_ms": (ms["bwd_dkv_finalize"][0] / ms["bwd_dkv_finalize"][1]) if ms["bwd_dkv_finalize"][1] else 0.0},
                                        "attention_fwd+bwd_14HqD": {"achieved": all_tf, "ms_per_step": attn_ms_total / max(args.steps, 1)}}},
     }
     if rank == 0:

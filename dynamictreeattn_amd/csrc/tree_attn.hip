@@ -771,7 +771,8 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   const int nkt = (Tk + p.ktile - 1) / p.ktile;
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();   // drop a stale error of an earlier, unrelated runtime call
-  if ((which & 3) == 0) return DTA_EINVAL;
+  if ((which & 7) == 0) return DTA_EINVAL;
+  const bool fin = ((which & 2) && !(which & 8)) || (which & 4);     // slab finalize: with the dK/dV launch unless bit3, or alone (bit2)
   // NG = 2 (two wave groups, two waves per SIMD) was measured at 0.52x the speed of NG = 1 on the tau2 trie: 128
   // accumulators + 64 K/V fragment registers do not fit 256 registers per wave (69 spills).  Not instantiated.
   const int ndkv = dkv_units ? n_units : nkt;
@@ -779,12 +780,12 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   const dim3 gq(pair ? nqt * Hq / 2 : nqt * Hq), bq(pair ? 512 : 256);
   if (dtype == DTA_BF16) {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 1>), gq, bq, 0, st, p); }
-    if (which & 2) { hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_BF16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
-                     if (dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_BF16>, dim3(n_splits * Hkv), dim3(256), 0, st, p); }
+    if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_BF16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
+    if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_BF16>, dim3(n_splits * Hkv), dim3(256), 0, st, p);
   } else {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 1>), gq, bq, 0, st, p); }
-    if (which & 2) { hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_F16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
-                     if (dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_F16>, dim3(n_splits * Hkv), dim3(256), 0, st, p); }
+    if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_F16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
+    if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_F16>, dim3(n_splits * Hkv), dim3(256), 0, st, p);
   }
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
 }

@@ -24,7 +24,7 @@ class KernelTimer:
     active: Optional["KernelTimer"] = None
 
     def __init__(self):
-        self.spans = {"fwd": [], "bwd_dq": [], "bwd_dkv": []}
+        self.spans = {"fwd": [], "bwd_dq": [], "bwd_dkv": [], "bwd_dkv_finalize": []}
 
     def span(self, name):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -113,7 +113,9 @@ def attn_bwd_raw(q, k, v, out, dout, lse, meta: TreeAttnMeta, scale: float, dk=N
     if tm is None:
         check(launch(3), "dta_tree_attn_bwd")
     else:
-        for which, name in ((1, "bwd_dq"), (2, "bwd_dkv")):
+        for which, name in ((1, "bwd_dq"), (2 | 8, "bwd_dkv"), (4, "bwd_dkv_finalize")):
+            if which == 4 and not n_splits:
+                continue
             a, b = tm.span(name); a.record(); st = launch(which); b.record()
             check(st, "dta_tree_attn_bwd")
     return dq, dk, dv

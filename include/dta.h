@@ -130,7 +130,8 @@ int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v, const void
                          int64_t o_stride_t, int64_t o_stride_h, int64_t dq_stride_t, int64_t dq_stride_h,
                          int64_t dkv_stride_t, int64_t dkv_stride_h,
                          float scale, int32_t dtype, int32_t accumulate,
-                         int32_t which /* bit0: delta+dq launch, bit1: dk/dv launch (needs delta) */,
+                         int32_t which /* bit0: delta+dq launch, bit1: dk/dv launch (needs delta) followed by the slab finalize
+                                          unless bit3; bit2: slab finalize alone (lets a profiler bracket each launch) */,
                          /* optional split of the dK/dV sweep into balanced work units (NULL: one per key tile):
                           * dkv_units[u] = {key tile, q_begin, q_end (packed), slab or -1}; units of a split key tile
                           * write fp32 slabs [2][DTA_KTILE][128] into dkv_ws (slab-major, then kv head) which a finalize

@@ -37,6 +37,8 @@ ms = tm.totals_ms(); ops.KernelTimer.active = None
 for name, coef in (("bwd_dq", 2), ("bwd_dkv", 8)):
     t = ms[name][0] / ms[name][1]
     res[name] = {"ms": round(t, 4), "TFLOPs": round(coef * Hq * D * pairs / (t * 1e-3) / 1e12, 1)}
-tot = res["fwd"]["ms"] + res["bwd_dq"]["ms"] + res["bwd_dkv"]["ms"]
+fin = ms["bwd_dkv_finalize"]
+res["bwd_dkv_finalize"] = {"ms": round(fin[0] / fin[1], 4) if fin[1] else 0.0}
+tot = res["fwd"]["ms"] + res["bwd_dq"]["ms"] + res["bwd_dkv"]["ms"] + res["bwd_dkv_finalize"]["ms"]
 res["all_14HqD"] = {"ms": round(tot, 4), "TFLOPs": round(14 * Hq * D * pairs / (tot * 1e-3) / 1e12, 1)}
 print(json.dumps({"case": case, "T": T, "pairs": pairs, **res}))
