@@ -208,3 +208,32 @@ def test_engine_accepts_a_huggingface_module_by_duck_typing(eng_gold):
     for n, p in hf.named_parameters():
         if n in g["bwd_bs2048_grads"]:
             assert mo.grad_ratio(g["bwd_bs2048_grads"][n], p.grad) <= 2e-5, n
+
+
+def test_dkv_work_units_partition_every_key_tile():
+    """packing.plan_dkv_units: the units of a key tile tile its query range exactly, in 64-row multiples,
+    split tiles get consecutive slabs listed in `splits`, heaviest units first."""
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        nkt = int(rng.integers(1, 60)); Tk = nkt * packing.KTILE - int(rng.integers(0, packing.KTILE))
+        Tq = Tk
+        kq = np.minimum(np.arange(nkt) * packing.KTILE + rng.integers(1, 40000, nkt), Tq).astype(np.int32)
+        kq = np.maximum(kq, np.minimum(np.arange(nkt) * packing.KTILE + 1, Tq)).astype(np.int32)
+        units, splits, n_slabs = packing.plan_dkv_units(kq, Tk, Tq, 0, Hkv=int(rng.integers(1, 9)))
+        assert units.dtype == np.int32 and units.shape[1] == 4
+        sizes = units[:, 2] - units[:, 1]
+        assert (np.diff(sizes) <= 0).all()                                  # heaviest first
+        slabs_seen = []
+        for kt in range(nkt):
+            u = units[units[:, 0] == kt]
+            u = u[np.argsort(u[:, 1])]
+            assert u[0, 1] == kt * packing.KTILE and u[-1, 2] == min(int(kq[kt]), Tq)
+            assert (u[1:, 1] == u[:-1, 2]).all() and ((u[:-1, 2] - u[:-1, 1]) % 64 == 0).all()
+            if len(u) > 1:
+                assert (np.diff(u[:, 3]) == 1).all()
+                row = splits[splits[:, 0] == kt][0]
+                assert row[1] == u[0, 3] and row[2] == len(u)
+                slabs_seen += u[:, 3].tolist()
+            else:
+                assert u[0, 3] == -1
+        assert sorted(slabs_seen) == list(range(n_slabs))
