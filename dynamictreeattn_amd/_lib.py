@@ -20,6 +20,7 @@ _PROTOS = {
     "dta_tree_attn_fwd_ex": ([_vp] * 8 + [_i32] * 6 + [_i64] * 8 + [_f32, _i32, _vp], C.c_int),
     "dta_tree_attn_bwd_ex": ([_vp] * 14 + [_i32] * 6 + [_i64] * 12 + [_f32, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp], C.c_int),
     "dta_logprob_entropy_fwd": ([_vp] * 5 + [_i32, _i32, _i64, _f32, _i32, _vp], C.c_int),
+    "dta_logprob_entropy_shard_stats": ([_vp] * 3 + [_i32, _i32, _i64, _f32, _i32, _vp], C.c_int),
     "dta_logprob_entropy_bwd": ([_vp] * 7 + [_i32, _i32, _i64, _f32, _i32, _vp], C.c_int),
     "dta_rmsnorm_fwd": ([_vp] * 6 + [_i32, _i32, _f32, _i32, _vp], C.c_int),
     "dta_rmsnorm_bwd_blocks": ([_i32], C.c_int),

@@ -46,7 +46,7 @@ __device__ __forceinline__ Stat block_reduce(Stat v, Stat* sh) {
 template <int DT>
 __global__ __launch_bounds__(256) void logprob_entropy_fwd_kernel(const void* __restrict__ logits_, const int64_t* __restrict__ labels,
                                                                   float* __restrict__ lse, float* __restrict__ ent, float* __restrict__ lp,
-                                                                  int R, int V, int64_t stride, float inv_temp) {
+                                                                  float* __restrict__ stats, int R, int V, int64_t stride, float inv_temp) {
   using e = typename LTy<DT>::e; using v8 = typename LTy<DT>::v8;
   __shared__ Stat sh[4];
   const int row = blockIdx.x;
@@ -72,7 +72,12 @@ __global__ __launch_bounds__(256) void logprob_entropy_fwd_kernel(const void* __
     st = Stat{m, st.s * f + p, __builtin_fmaf(p, y, st.t * f)};
   }
   st = block_reduce(st, sh);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && stats) {
+    // vocab-sharded use: raw per-shard statistics (log2 domain of the scaled logits) for a cross-rank combine
+    const int64_t lab = labels ? labels[row] : -1;
+    stats[4 * row] = st.m; stats[4 * row + 1] = st.s; stats[4 * row + 2] = st.t;
+    stats[4 * row + 3] = (lab >= 0 && lab < V) ? (float)x[lab] * inv_temp : 0.f;
+  } else if (threadIdx.x == 0) {
     const float lse2 = st.m + __builtin_amdgcn_logf(st.s);               // log2 domain
     const float l = lse2 * LN2;
     lse[row] = l;
@@ -121,15 +126,34 @@ __global__ __launch_bounds__(256) void logprob_entropy_bwd_kernel(void* __restri
 
 }  // namespace
 
+static int logprob_fwd_launch(const void* logits, const int64_t* labels, float* lse, float* entropy, float* logprob, float* stats,
+                              int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream);
+
 extern "C" int dta_logprob_entropy_fwd(const void* logits, const int64_t* labels, float* lse, float* entropy, float* logprob,
                                        int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream) {
-  if (!logits || !lse || R <= 0 || V <= 0 || (logprob && !labels) || !(temperature > 0.f)) return DTA_EINVAL;
+  if (!lse) return DTA_EINVAL;
+  return logprob_fwd_launch(logits, labels, lse, entropy, logprob, nullptr, R, V, row_stride, temperature, dtype, stream);
+}
+
+/* Vocab-sharded variant: stats[r] = {m, s, t, picked} of THIS shard — m = max_j y_j, s = sum 2^(y_j-m),
+ * t = sum 2^(y_j-m)*y_j with y = x*log2(e)/T, picked = x[labels[r]]/T if 0 <= labels[r] < V (labels are
+ * shard-local, -1 = owned elsewhere) else 0.  Ranks combine them (MAX of m, then SUM of rescaled s, t, picked):
+ * the arithmetic of vocab_parallel.py:125-160 / 258-300 with one packed SUM all-reduce. */
+extern "C" int dta_logprob_entropy_shard_stats(const void* logits, const int64_t* labels, float* stats,
+                                               int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream) {
+  if (!stats) return DTA_EINVAL;
+  return logprob_fwd_launch(logits, labels, nullptr, nullptr, nullptr, stats, R, V, row_stride, temperature, dtype, stream);
+}
+
+static int logprob_fwd_launch(const void* logits, const int64_t* labels, float* lse, float* entropy, float* logprob, float* stats,
+                              int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream) {
+  if (!logits || R <= 0 || V <= 0 || (logprob && !labels) || !(temperature > 0.f)) return DTA_EINVAL;
   if (dtype != DTA_BF16 && dtype != DTA_F16) return DTA_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(logits) & 15) || (row_stride % 8)) return DTA_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();
-  if (dtype == DTA_BF16) hipLaunchKernelGGL(logprob_entropy_fwd_kernel<DTA_BF16>, dim3(R), dim3(256), 0, st, logits, labels, lse, entropy, logprob, R, V, row_stride, 1.f / temperature);
-  else hipLaunchKernelGGL(logprob_entropy_fwd_kernel<DTA_F16>, dim3(R), dim3(256), 0, st, logits, labels, lse, entropy, logprob, R, V, row_stride, 1.f / temperature);
+  if (dtype == DTA_BF16) hipLaunchKernelGGL(logprob_entropy_fwd_kernel<DTA_BF16>, dim3(R), dim3(256), 0, st, logits, labels, lse, entropy, logprob, stats, R, V, row_stride, 1.f / temperature);
+  else hipLaunchKernelGGL(logprob_entropy_fwd_kernel<DTA_F16>, dim3(R), dim3(256), 0, st, logits, labels, lse, entropy, logprob, stats, R, V, row_stride, 1.f / temperature);
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
 }
 

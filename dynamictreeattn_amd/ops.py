@@ -191,44 +191,92 @@ def logprob_entropy_bwd_raw(logits, labels, lse, ent, g_lp, g_extra, g_ent, temp
     return logits
 
 
+def logprob_entropy_shard_stats_raw(logits, labels_local, temperature=1.0):
+    """Per-shard statistics [R,4] = {m, s, t, picked} (log2 domain) of logits [R, V/tp]; see dta.h."""
+    _require_cuda(logits)
+    R, V = logits.shape
+    stats = torch.empty((R, 4), dtype=torch.float32, device=logits.device)
+    check(lib().dta_logprob_entropy_shard_stats(ptr(logits), ptr(labels_local), ptr(stats), R, V, logits.stride(0),
+                                                float(temperature), _DT[logits.dtype], _stream()), "dta_logprob_entropy_shard_stats")
+    return stats
+
+
+_LN2 = 0.6931471805599453
+
+
+def _combine_shard_stats(stats, extra_sum, group):
+    """Cross-rank combine of the per-shard statistics: ONE MAX all-reduce, then ONE packed SUM all-reduce
+    (s, t, picked and `extra_sum`, the raw logits picked for fork children) — vocab_parallel.py:134,142,156 /
+    264,273,291,298 issue 3-4 separate latency-bound reductions per chunk.  Returns (lse, ent, picked, extra)."""
+    import torch.distributed as dist
+    m = stats[:, 0].contiguous()
+    M = m.clone()
+    dist.all_reduce(M, op=dist.ReduceOp.MAX, group=group)
+    f = torch.exp2(m - M)
+    R = stats.shape[0]
+    packed = torch.cat([stats[:, 1] * f, stats[:, 2] * f, stats[:, 3], extra_sum])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    S, Tt, picked, extra = packed[:R], packed[R:2 * R], packed[2 * R:3 * R], packed[3 * R:]
+    lse = (M + torch.log2(S)) * _LN2
+    ent = lse - (Tt / S) * _LN2
+    return lse, ent, picked, extra
+
+
 class _HeadRows(torch.autograd.Function):
     """(lp_next [T], lp_fork [F], ent [T]) from hidden rows: lp_next[r] = log p(next_tok[r] | row r),
     lp_fork[f] = log p(fork_tok[f] | row fork_rows[f]).  When the model-dtype [T, V] logits fit
     `keep_bytes` they are produced by ONE GEMM, kept, turned into dLoss/dlogits IN PLACE in backward and
     consumed by one dgrad and one wgrad GEMM.  Otherwise rows go `chunk` at a time and the logits of a
-    chunk are recomputed in backward (at most one [chunk, V] block alive)."""
+    chunk are recomputed in backward (at most one [chunk, V] block alive).
+    With `tp_group`, W is this rank's contiguous vocabulary slice starting at `vocab_offset` (labels stay global,
+    vocab_parallel.py:128-130): per-shard statistics from the HIP kernel are combined with two all-reduces per
+    chunk and the hidden-state gradient is summed across the group."""
 
     @staticmethod
-    def forward(ctx, h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes):
+    def forward(ctx, h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes, tp_group, vocab_offset):
         T = h.shape[0]
         dev = h.device
         V = W.shape[0]
         keep = T * V * h.element_size() <= keep_bytes
         step = T if keep else chunk
         lse = torch.empty(T, dtype=torch.float32, device=dev)
-        ent = torch.empty(T, dtype=torch.float32, device=dev) if want_entropy else None
+        ent = torch.empty(T, dtype=torch.float32, device=dev) if (want_entropy or tp_group is not None) else None
         lp_next = torch.empty(T, dtype=torch.float32, device=dev)
         lp_fork = torch.empty(fork_rows.numel(), dtype=torch.float32, device=dev)
+        if tp_group is not None:       # shard-local label ids; -1 = owned by another rank
+            own = lambda t: torch.where((t >= vocab_offset) & (t < vocab_offset + V), t - vocab_offset, torch.full_like(t, -1))
+            next_loc, fork_loc = own(next_tok), own(fork_tok)
+        else:
+            next_loc, fork_loc = next_tok, fork_tok
         kept = None
         for ci, a in enumerate(range(0, T, step)):
             b = min(a + step, T)
             logits = torch.mm(h[a:b], W.t())
-            l, e, p = logprob_entropy_fwd_raw(logits, next_tok[a:b], want_entropy)
-            lse[a:b] = l; lp_next[a:b] = p
-            if want_entropy:
-                ent[a:b] = e
             f0, f1 = (0, fork_rows.numel()) if keep else (fork_bounds[ci], fork_bounds[ci + 1])
-            if f1 > f0:
-                lp_fork[f0:f1] = logits[fork_rows[f0:f1] - a, fork_tok[f0:f1]].float() - l[fork_rows[f0:f1] - a]
+            if tp_group is None:
+                l, e, p = logprob_entropy_fwd_raw(logits, next_loc[a:b], want_entropy)
+                if f1 > f0:
+                    lp_fork[f0:f1] = logits[fork_rows[f0:f1] - a, fork_tok[f0:f1]].float() - l[fork_rows[f0:f1] - a]
+            else:
+                stats = logprob_entropy_shard_stats_raw(logits, next_loc[a:b])
+                fl = fork_loc[f0:f1]
+                raw = torch.where(fl >= 0, logits[fork_rows[f0:f1] - a, fl.clamp(min=0)].float(), torch.zeros(f1 - f0, device=dev))
+                l, e, picked, raw = _combine_shard_stats(stats, raw, tp_group)
+                p = picked - l
+                if f1 > f0:
+                    lp_fork[f0:f1] = raw - l[fork_rows[f0:f1] - a]
+            lse[a:b] = l; lp_next[a:b] = p
+            if ent is not None:
+                ent[a:b] = e
             if keep:
                 kept = logits
-        ctx.save_for_backward(h, W, next_tok, fork_rows, fork_tok, lse, ent if want_entropy else lse)
-        ctx.kept, ctx.chunk, ctx.fork_bounds, ctx.want_entropy = kept, chunk, fork_bounds, want_entropy
+        ctx.save_for_backward(h, W, next_loc, fork_rows, fork_loc, lse, ent if ent is not None else lse)
+        ctx.kept, ctx.chunk, ctx.fork_bounds, ctx.want_entropy, ctx.tp_group = kept, chunk, fork_bounds, want_entropy, tp_group
         return lp_next, lp_fork, (ent if want_entropy else lse.new_zeros(0))
 
     @staticmethod
     def backward(ctx, g_next, g_fork, g_ent):
-        h, W, next_tok, fork_rows, fork_tok, lse, ent = ctx.saved_tensors
+        h, W, next_loc, fork_rows, fork_loc, lse, ent = ctx.saved_tensors
         T = h.shape[0]
         fb = ctx.fork_bounds
         g_next = g_next.contiguous().float()
@@ -244,27 +292,33 @@ class _HeadRows(torch.autograd.Function):
         for ci, a in enumerate(range(0, T, step)):
             b = min(a + step, T)
             logits = kept if kept is not None else torch.mm(h[a:b], W.t())
-            logprob_entropy_bwd_raw(logits, next_tok[a:b], lse[a:b], ent[a:b] if ctx.want_entropy else None, g_next[a:b],
+            logprob_entropy_bwd_raw(logits, next_loc[a:b], lse[a:b], ent[a:b] if ctx.want_entropy else None, g_next[a:b],
                                     g_extra[a:b] if g_extra is not None else None, g_ent[a:b] if ctx.want_entropy else None)
             f0, f1 = (0, fork_rows.numel()) if kept is not None else (fb[ci], fb[ci + 1])
             if f1 > f0:
-                logits.index_put_((fork_rows[f0:f1] - a, fork_tok[f0:f1]), g_fork[f0:f1].to(logits.dtype), accumulate=True)
+                fl = fork_loc[f0:f1]
+                mine = fl >= 0                                   # one-hot terms only on the rank that owns the token
+                logits.index_put_((fork_rows[f0:f1][mine] - a, fl[mine]), g_fork[f0:f1][mine].to(logits.dtype), accumulate=True)
             torch.mm(logits, W, out=dh[a:b])
             if kept is not None:
                 dW = torch.mm(logits.t(), h)                 # one wgrad GEMM over all T rows (fp32 accumulate inside)
             else:
                 dW += torch.mm(logits.t(), h[a:b])
         ctx.kept = None
-        return dh, dW.to(W.dtype), None, None, None, None, None, None, None
+        if ctx.tp_group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(dh, op=dist.ReduceOp.SUM, group=ctx.tp_group)      # each rank saw only its vocabulary slice
+        return dh, dW.to(W.dtype), None, None, None, None, None, None, None, None, None
 
 
-def lm_head_rows(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes=None):
+def lm_head_rows(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes=None, tp_group=None, vocab_offset=0):
     """See _HeadRows.  `fork_bounds[c] .. fork_bounds[c+1]` = the forks whose row lies in chunk c (host list)."""
     _require_cuda(h, W)
     if keep_bytes is None:
         free, _ = torch.cuda.mem_get_info(h.device)
         keep_bytes = free // 4
-    lp_next, lp_fork, ent = _HeadRows.apply(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes)
+    lp_next, lp_fork, ent = _HeadRows.apply(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes,
+                                            tp_group, vocab_offset)
     return lp_next, lp_fork, (ent if want_entropy else None)
 
 

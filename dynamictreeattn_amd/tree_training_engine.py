@@ -53,7 +53,7 @@ def _get_forkpos(lens, lcp_lens, block_size: Optional[int]) -> list:
 # --------------------------------------------------------------------------------------------------
 def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tensor, parent: torch.Tensor,
                            want_entropy: bool, chunk: int = 2048, fork_child: Optional[np.ndarray] = None,
-                           fork_parent: Optional[np.ndarray] = None):
+                           fork_parent: Optional[np.ndarray] = None, tp_group=None):
     """lp[t] = log softmax(h[parent[t]] Wᵀ)[tokens[t]] (0 for roots), ent[t] = H(softmax(h[t] Wᵀ)); fp32.
     The arithmetic (vocab_parallel.py:13-27; call sites tte:190-193, 256-261, 361-372) runs in
     `ops.lm_head_rows`: hipBLASLt logits GEMM per row chunk + the HIP statistics kernels; at most one
@@ -70,7 +70,17 @@ def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tenso
     ftok = tokens[fc_dev] if fork_child.size else tokens.new_zeros(0)
     nxt = torch.cat([tokens[1:], tokens.new_zeros(1)])
     bounds = np.searchsorted(fork_parent, np.arange(0, T + chunk, chunk)).tolist()
-    lp_next, lp_fork, ent = ops.lm_head_rows(h, W, nxt, fp_dev, ftok, bounds, want_entropy, chunk)
+    if tp_group is not None:
+        # vocabulary split across the group (BASELINE config 4; vocab_parallel.py:128-130): this rank multiplies by
+        # its contiguous slice of the (tied) head weight only; labels stay global
+        import torch.distributed as dist
+        tp, rk = dist.get_world_size(tp_group), dist.get_rank(tp_group)
+        Vp = W.shape[0] // tp
+        assert Vp * tp == W.shape[0], "vocabulary must divide by the tensor-parallel size"
+        lp_next, lp_fork, ent = ops.lm_head_rows(h, W[rk * Vp:(rk + 1) * Vp], nxt, fp_dev, ftok, bounds, want_entropy, chunk,
+                                                 tp_group=tp_group, vocab_offset=rk * Vp)
+    else:
+        lp_next, lp_fork, ent = ops.lm_head_rows(h, W, nxt, fp_dev, ftok, bounds, want_entropy, chunk)
     chain = torch.zeros(T, dtype=torch.bool, device=dev)           # lp_next[r] = log p(tokens[r+1] | node r)
     chain[1:] = parent[1:] == torch.arange(0, T - 1, device=dev, dtype=parent.dtype)
     lp = torch.cat([lp_next.new_zeros(1), lp_next[:-1]]) * chain
@@ -143,6 +153,7 @@ class TreeTrainingEngine:
         self.last_packed: Optional[_PackedTrie] = None
         self.head_chunk = 2048
         self.checkpoint_layers: Optional[bool] = None    # None = decide from free HBM
+        self.tp_group = None                             # set to a process group to split the LM-head vocabulary across it
 
     # ------------------------------------------------------------------------------------------
     def _pack(self, token_trie) -> _PackedTrie:
@@ -186,7 +197,7 @@ class TreeTrainingEngine:
         packed = self._pack(token_trie)
         h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, False)
         lp, _ = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, False, self.head_chunk,
-                                       packed.fork_child, packed.fork_parent)
+                                       packed.fork_child, packed.fork_parent, self.tp_group)
         for i, attach_list in enumerate(token_trie.attach_lists):
             lp_path = lp[packed.paths[i][1:]]
             for attachment, length in attach_list:
@@ -204,7 +215,7 @@ class TreeTrainingEngine:
         chunk = min(self.head_chunk, block_size) if block_size else self.head_chunk
         h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, self._should_checkpoint(model, packed.plan.T))
         lp, ent = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, True, max(chunk, 1),
-                                         packed.fork_child, packed.fork_parent)
+                                         packed.fork_child, packed.fork_parent, self.tp_group)
         total = self._path_losses(packed, token_trie, lp, ent, loss_fn)
         if total is None:
             return 0.0

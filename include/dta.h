@@ -148,6 +148,10 @@ int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v, const void
  * Replaces vocab_parallel.py:13-27 (_gather_logprobs[_entropy]) and its autograd backward.  */
 int dta_logprob_entropy_fwd(const void* logits, const int64_t* labels, float* lse, float* entropy, float* logprob,
                             int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream);
+/* Vocab-sharded forward: raw per-shard statistics stats[R][4] = {m, s, t, picked} (log2 domain of x*log2(e)/T;
+ * labels shard-local, -1 = owned by another rank) for the cross-rank combine of vocab_parallel.py:125-160, 258-300. */
+int dta_logprob_entropy_shard_stats(const void* logits, const int64_t* labels, float* stats,
+                                    int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream);
 int dta_logprob_entropy_bwd(void* logits_inout, const int64_t* labels, const float* lse, const float* entropy,
                             const float* g_logprob, const float* g_extra, const float* g_entropy,
                             int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream);

@@ -75,3 +75,62 @@ def test_lm_head_rows_vs_plain_torch():
         for i, (x, y) in enumerate(zip(got, ref)):
             tol = 3e-3 if i < 3 else 2e-2
             assert float((x - y).norm() / (y.norm() + 1e-9)) <= tol, (keep, i)
+
+
+def _tp_worker(rank, world, port, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks share the one GPU of the box: gloo, not RCCL
+    from dynamictreeattn_amd import ops as _ops
+    g = torch.Generator().manual_seed(0)
+    T, H, V = 300, 64, 1024
+    h = (torch.randn(T, H, generator=g) * 0.5).bfloat16().to(DEV).requires_grad_(True)
+    W = (torch.randn(V, H, generator=g) * 0.2).bfloat16().to(DEV)
+    nxt = torch.randint(0, V, (T,), generator=g).to(DEV)
+    fork_rows = torch.tensor([3, 3, 250, 299]).to(DEV); fork_tok = torch.randint(0, V, (4,), generator=g).to(DEV)
+    go = [torch.randn(n, generator=g).to(DEV) for n in (T, 4, T)]
+    Vp = V // world
+    Ws = W[rank * Vp:(rank + 1) * Vp].clone().requires_grad_(True)
+    out = {}
+    for keep in (1 << 40, 0):
+        chunk = 128
+        bounds = np.searchsorted(fork_rows.cpu().numpy(), np.arange(0, T + chunk, chunk)).tolist()
+        h.grad = None; Ws.grad = None
+        a, b, c = _ops.lm_head_rows(h, Ws, nxt, fork_rows, fork_tok, bounds, True, chunk, keep, tp_group=dist.group.WORLD, vocab_offset=rank * Vp)
+        ((a * go[0]).sum() + (b * go[1]).sum() + (c * go[2]).sum()).backward()
+        out[keep] = [t.detach().float().cpu() for t in (a, b, c, h.grad, Ws.grad)]
+    torch.save(out, os.path.join(outdir, f"tp{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_vocab_sharded_lm_head_two_ranks_vs_unsharded(tmp_path):
+    """Config 4's logit split: two gloo ranks (sharing this box's GPU) each hold half of the vocabulary; per-shard
+    HIP statistics + 2 all-reduces must reproduce the unsharded operator (values, dh, and dW on the own slice)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    [p.start() for p in procs]; [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    g = torch.Generator().manual_seed(0)
+    T, H, V = 300, 64, 1024
+    h = (torch.randn(T, H, generator=g) * 0.5).bfloat16().to(DEV).requires_grad_(True)
+    W = (torch.randn(V, H, generator=g) * 0.2).bfloat16().to(DEV).requires_grad_(True)
+    nxt = torch.randint(0, V, (T,), generator=g).to(DEV)
+    fork_rows = torch.tensor([3, 3, 250, 299]).to(DEV); fork_tok = torch.randint(0, V, (4,), generator=g).to(DEV)
+    go = [torch.randn(n, generator=g).to(DEV) for n in (T, 4, T)]
+    bounds = np.searchsorted(fork_rows.cpu().numpy(), np.arange(0, T + 128, 128)).tolist()
+    a, b, c = ops.lm_head_rows(h, W, nxt, fork_rows, fork_tok, bounds, True, 128, 1 << 40)
+    ((a * go[0]).sum() + (b * go[1]).sum() + (c * go[2]).sum()).backward()
+    ref = [t.detach().float().cpu() for t in (a, b, c, h.grad)]
+    for rank in (0, 1):
+        res = torch.load(os.path.join(str(tmp_path), f"tp{rank}.pt"), weights_only=True)
+        for keep, got in res.items():
+            for i in range(3):
+                assert (got[i] - ref[i]).abs().max() <= 2e-3 * (1 + ref[i].abs().max()), (rank, keep, i)
+            assert float((got[3] - ref[3]).norm() / ref[3].norm()) <= 1.5e-2
+            dW_ref = W.grad.float().cpu()[rank * 512:(rank + 1) * 512]
+            assert float((got[4] - dW_ref).norm() / dW_ref.norm()) <= 1.5e-2
