@@ -17,7 +17,6 @@ import json
 import os
 import sys
 import time
-import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -9,8 +9,6 @@ prefix (hf: models/qwen3/modeling_qwen3.py:262-280) — exactly the stack form o
 """
 from __future__ import annotations
 
-import torch
-
 from . import ops
 
 NAME = "dta_mi355x"

@@ -12,9 +12,7 @@ torch.  `Qwen3TreeLM` mirrors the HF module/parameter tree (``model.embed_tokens
 """
 from __future__ import annotations
 
-import math
 from types import SimpleNamespace
-from typing import Optional
 
 import torch
 import torch.nn as nn

@@ -23,7 +23,6 @@ left to cut (no token is forwarded twice) and is accepted for signature parity.
 """
 from __future__ import annotations
 
-from math import ceil
 from typing import Callable, List, Optional
 
 import numpy as np

@@ -10,7 +10,7 @@ Iterative throughout (the reference recurses: Python's recursion limit caps its 
 from __future__ import annotations
 
 import random as _random
-from typing import Iterable, List, Optional, Sequence, Tuple
+from typing import Iterable, List, Optional, Sequence
 
 __all__ = ["CTNode", "CompressedTrie", "_get_stats", "_get_subtrie", "pop_block_starts"]
 

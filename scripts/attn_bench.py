@@ -3,8 +3,8 @@
 (Qwen3-0.6B head geometry), random data, HIP-event timed.  Usage: python scripts/attn_bench.py [iters] [case]"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from dynamictreeattn_amd import ops, packing, synth
+import torch
+from dynamictreeattn_amd import ops, synth
 from dynamictreeattn_amd.token_trie import TokenTrie
 from dynamictreeattn_amd.tree_training_engine import _PackedTrie
 

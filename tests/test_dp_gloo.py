@@ -6,7 +6,6 @@ unsharded one and the reference's recorded values."""
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist

@@ -131,7 +131,6 @@ def test_hf_attention_interface_plugin_matches_eager():
     """An unmodified transformers Qwen3 with attn_implementation="dta_mi355x" (prefix K/V through a
     DynamicCache, as the reference engine calls it) against its own eager backend."""
     transformers = pytest.importorskip("transformers")
-    from transformers.cache_utils import DynamicCache
     from dynamictreeattn_amd import hf_attention
     name = hf_attention.register()
     cfg = synth.TINY_CFGS["d128"]

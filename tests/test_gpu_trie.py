@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import hostmirror
-from dynamictreeattn_amd import packing, synth
+from dynamictreeattn_amd import synth
 from dynamictreeattn_amd.token_trie import TokenTrie, _DeviceTokens, _device_trie_arrays
 from oracle import trie_oracle as to
 
