@@ -171,6 +171,12 @@ __device__ __forceinline__ FragOffs frag_offsets(int lane) {
   }
   return o;
 }
+template <class V8> __device__ __forceinline__ V8 tr_pair(const char* lo_p, const char* hi_p) {
+  s16x4 lo = tr_read(lo_p);
+  s16x4 hi = tr_read(hi_p);
+  s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(V8, both);
+}
 template <class V8> __device__ __forceinline__ V8 tr_frag_o(const char* img_r0, const FragOffs& o, int mb) {
   s16x4 lo = tr_read(img_r0 + o.tr[mb]);
   s16x4 hi = tr_read(img_r0 + o.tr[4 + mb]);
@@ -473,7 +479,8 @@ __global__ __launch_bounds__(256 * NG) void tree_attn_bwd_dkv_kernel(AttnParams 
   // NG = 2: two groups of 4 waves (two waves per SIMD) own the SAME keys and take alternate items of the
   // (query head, query tile) sweep through their own double-buffered Q/dO images; their partial dK/dV are
   // summed through LDS at the end in a fixed order.
-  const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x & 255, grp = NG == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform values live in SGPRs: scalar address arithmetic
   char* smem = smem_all + grp * KV_LDS;
   const int bid = blockIdx.x;
   const int kvh = bid % p.Hkv; const int unit = bid / p.Hkv;
@@ -506,8 +513,9 @@ __global__ __launch_bounds__(256 * NG) void tree_attn_bwd_dkv_kernel(AttnParams 
     for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
     if (lane == 0 && grp == 0) se_min_s[wave] = mn; }
   __syncthreads();
-  const int se_min = min(min(se_min_s[0], se_min_s[1]), min(se_min_s[2], se_min_s[3]));
+  const int se_min = __builtin_amdgcn_readfirstlane(min(min(se_min_s[0], se_min_s[1]), min(se_min_s[2], se_min_s[3])));
 
+  const FragOffs offs = frag_offsets(lane);
   f32x16 DK[KB][4], DV[KB][4];
 #pragma unroll
   for (int b = 0; b < KB; ++b)
@@ -517,83 +525,115 @@ __global__ __launch_bounds__(256 * NG) void tree_attn_bwd_dkv_kernel(AttnParams 
       for (int g = 0; g < 16; ++g) { DK[b][db][g] = 0.f; DV[b][db][g] = 0.f; }
 
   int qbeg, qend;
-  if (p.dkv_units) { qbeg = p.dkv_units[4 * unit + 1]; qend = p.dkv_units[4 * unit + 2]; }
+  if (p.dkv_units) { qbeg = __builtin_amdgcn_readfirstlane(p.dkv_units[4 * unit + 1]); qend = __builtin_amdgcn_readfirstlane(p.dkv_units[4 * unit + 2]); }
   else {
     qbeg = k0 > p.q_offset ? k0 : p.q_offset;                        // packed index of the first query that can see a key here
     qend = p.ktile_qend ? p.ktile_qend[kt] : q_hi; qend = qend < q_hi ? qend : q_hi;
   }
   const int ntile = qend > qbeg ? (qend - qbeg + 63) / 64 : 0;
   const int total = ntile * p.group;
-  const float c = p.scale * LOG2E, inv_c = 1.f / c;
+  const float c = p.scale * LOG2E;
 
   // Q / dO tiles go global -> LDS directly (LDS-DMA, no staging registers, no ds_write): a wave instruction
   // lands 64 x 16 B = 4 image rows lane-linearly, so the XOR swizzle of the image is applied to the per-lane
-  // SOURCE chunk instead (the read side uses the same involution).  lse / delta*scale are 64 floats each and
-  // take the ordinary path BEFORE the DMA is issued (an ordinary load behind a DMA would drain it).
-#define KV_DMA(IDX, B)                                                                                     \
-  { const int hg_ = (IDX) / ntile, ti_ = (IDX) - hg_ * ntile; const int hq_ = kvh * p.group + hg_;         \
-    const int row0_ = qbeg + 64 * ti_ - p.q_offset;                                                        \
+  // SOURCE chunk instead (the read side uses the same involution).  lse / delta are 64 floats each and go by
+  // 4-byte DMA from waves 0 / 1 (an ordinary load + ds_write would stall those waves for a full memory latency per tile).
+  // Per-lane byte offsets of this lane's 16-B chunk inside a 64-row tile are fixed for the whole sweep (piece i of this
+  // wave covers image rows 16*wave + 4*i .. +3); per tile only the UNIFORM base moves, so the DMA takes the
+  // scalar-base + 32-bit-lane-offset form and costs no per-lane address arithmetic in the loop.
+  uint32_t voff_q[4], voff_d[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row_ = 16 * wave + 4 * i + (lane >> 4);
+    const int ch_ = (lane & 15) ^ (((lane >> 4) << 2) | i);              // (row_ & 3) = lane >> 4, (row_ >> 2) & 3 = i
+    voff_q[i] = (uint32_t)((row_ * p.q_st + ch_ * 8) * (int64_t)sizeof(e));
+    voff_d[i] = (uint32_t)((row_ * p.o_st + ch_ * 8) * (int64_t)sizeof(e));
+  }
+#define KV_DMA(HG, TI, B)                                                                                  \
+  { const int hq_ = __builtin_amdgcn_readfirstlane(kvh * p.group + (HG));                                   \
+    const int row0_ = qbeg + 64 * (TI) - p.q_offset;                                                       \
     char* base_ = smem + (B) * (2 * TILE_BYTES + 512);                                                     \
-    if (tid < 128) { int qr_ = row0_ + (tid & 63); qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;                      \
-      reinterpret_cast<float*>(base_ + 2 * TILE_BYTES)[tid] =                                              \
-          tid < 64 ? -p.lse_r[(int64_t)hq_ * p.Tq + qr_] * inv_c : -p.delta[(int64_t)hq_ * p.Tq + qr_]; }     \
-    const e* qb_ = reinterpret_cast<const e*>(p.q) + (int64_t)hq_ * p.q_sh;                                \
-    const e* db_ = reinterpret_cast<const e*>(p.dout) + (int64_t)hq_ * p.o_sh;                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
-      const int piece_ = wave * 4 + i_, row_ = 4 * piece_ + (lane >> 4);                                   \
-      const int ch_ = (lane & 15) ^ (((row_ & 3) << 2) | ((row_ >> 2) & 3));                                \
-      int qr_ = row0_ + row_; qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;                                           \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb_ + (int64_t)qr_ * p.q_st + ch_ * 8), \
-                                       (__attribute__((address_space(3))) void*)(base_ + piece_ * 1024), 16, 0, 0);            \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + (int64_t)qr_ * p.o_st + ch_ * 8), \
-                                       (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + piece_ * 1024), 16, 0, 0); } }
+    if (wave < 2) { int qr_ = row0_ + lane; qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;   /* wave 0: lse[64], wave 1: delta[64] */ \
+      const float* src_ = (wave == 0 ? p.lse_r : p.delta) + (int64_t)hq_ * p.Tq;                           \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + qr_),        \
+                                       (__attribute__((address_space(3))) void*)(base_ + 2 * TILE_BYTES + wave * 256), 4, 0, 0); } \
+    const char* qb_ = reinterpret_cast<const char*>(p.q) + ((int64_t)hq_ * p.q_sh + (int64_t)row0_ * p.q_st) * (int64_t)sizeof(e);    \
+    const char* db_ = reinterpret_cast<const char*>(p.dout) + ((int64_t)hq_ * p.o_sh + (int64_t)row0_ * p.o_st) * (int64_t)sizeof(e); \
+    if (row0_ + 64 <= p.Tq) {                                                                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb_ + voff_q[i_]), \
+                                         (__attribute__((address_space(3))) void*)(base_ + (wave * 4 + i_) * 1024), 16, 0, 0);              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + voff_d[i_]), \
+                                         (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + (wave * 4 + i_) * 1024), 16, 0, 0); } \
+    } else {                                       /* ragged last tile of the tensor: clamp the row per lane */ \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
+        const int row_ = 16 * wave + 4 * i_ + (lane >> 4);                                                 \
+        const int ch_ = (lane & 15) ^ (((lane >> 4) << 2) | i_);                                           \
+        const int rr_ = row0_ + row_ < p.Tq ? row_ : p.Tq - 1 - row0_;                                     \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb_ + ((int64_t)rr_ * p.q_st + ch_ * 8) * (int64_t)sizeof(e)), \
+                                         (__attribute__((address_space(3))) void*)(base_ + (wave * 4 + i_) * 1024), 16, 0, 0);              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + ((int64_t)rr_ * p.o_st + ch_ * 8) * (int64_t)sizeof(e)), \
+                                         (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + (wave * 4 + i_) * 1024), 16, 0, 0); } } }
 
   const int niter = (total + NG - 1) / NG;               // same barrier count in every group
   {
-    if (grp < total) KV_DMA(grp, 0)
+    int hg_c = 0, ti_c = grp;                        // (query head of the group, query tile) of item idx, advanced without division
+    while (ntile > 0 && ti_c >= ntile) { ti_c -= ntile; ++hg_c; }
+    if (grp < total) KV_DMA(hg_c, ti_c, 0)
     __syncthreads();                                 // hipcc drains the DMA (vmcnt(0)) in front of the barrier
     int cur = 0;
     for (int it_ = 0; it_ < niter; ++it_) {
       const int idx = it_ * NG + grp;
-      if (idx + NG < total) KV_DMA(idx + NG, cur ^ 1)  // buffer cur^1 was last read before the previous barrier
+      const int ti = ti_c;
+      ti_c += NG;
+      while (ti_c >= ntile) { ti_c -= ntile; ++hg_c; }
+      if (idx + NG < total) KV_DMA(hg_c, ti_c, cur ^ 1)  // buffer cur^1 was last read before the previous barrier
       if (NG == 1 || idx < total) {
-      const char* Qs = smem + cur * (2 * TILE_BYTES + 512); const char* Ds = Qs + TILE_BYTES;
+      const char* Qs = smem + cur * (2 * TILE_BYTES + 512);
       const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * TILE_BYTES); const float* del_s = lse_s + 64;
-      const int ti = idx % ntile;
       const int qi0 = qbeg + 64 * ti;                                   // packed index of image row 0
       const bool full = (qi0 >= k0 + KT - 1) && (qi0 + 63 < se_min);        // workgroup-uniform: no mask needed
-      // one 32-row query block at a time
-#pragma unroll
+      // one 32-row query block at a time (NOT unrolled: both blocks then share one S/dP register set; unrolled, hipcc
+      // parks a dK/dV tile in VGPRs around the first block, 64 extra accumulator moves per tile)
+#pragma unroll 1
       for (int qb = 0; qb < 2; ++qb) {
-        // row constants as the INITIAL accumulators: S starts at -lse/c and dP at -delta, so after the MFMA
-        // chains  p = exp2(c*S)  and  dS = p*dP*scale  need no per-row operands in registers
+        // every LDS read below is <address register> + <immediate>: 16 adds of the (buffer, block) base per block
+        const int sb = cur * (2 * TILE_BYTES + 512) + qb * (32 * 256);
+        int ar[8], at[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ar[j] = offs.row[j] + sb; at[j] = offs.tr[j] + sb; }
+        // S and dP start at 0 (inline constant, no register traffic):  p = exp2(c*S - lse),  dS/scale = p*(dP - delta);
+        // the softmax scale of dS is applied once to the dK accumulators in the epilogue
         f32x16 S[KB], DP[KB];
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) { S[b][g] = 0.f; DP[b][g] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const v8 aq = *reinterpret_cast<const v8*>(smem + ar[s]);
+          const v8 ad = *reinterpret_cast<const v8*>(smem + ar[s] + TILE_BYTES);
+#pragma unroll
+          for (int b = 0; b < KB; ++b) { S[b] = T::mma(aq, kf[b][s], S[b]); DP[b] = T::mma(ad, vf[b][s], DP[b]); }
+        }
+        // row constants come from LDS only now, after the MFMA chains: they occupy registers for the VALU phase alone
+        float nl[16], dl[16];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int ql = 32 * qb + 8 * gq + 4 * h;
           const float4 l4 = *reinterpret_cast<const float4*>(lse_s + ql);
           const float4 d4 = *reinterpret_cast<const float4*>(del_s + ql);
-#pragma unroll
-          for (int b = 0; b < KB; ++b) {
-            S[b][4 * gq] = l4.x; S[b][4 * gq + 1] = l4.y; S[b][4 * gq + 2] = l4.z; S[b][4 * gq + 3] = l4.w;
-            DP[b][4 * gq] = d4.x; DP[b][4 * gq + 1] = d4.y; DP[b][4 * gq + 2] = d4.z; DP[b][4 * gq + 3] = d4.w;
-          }
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const v8 aq = row_frag<v8>(Qs, 32 * qb + r, 2 * s + h);
-          const v8 ad = row_frag<v8>(Ds, 32 * qb + r, 2 * s + h);
-#pragma unroll
-          for (int b = 0; b < KB; ++b) { S[b] = T::mma(aq, kf[b][s], S[b]); DP[b] = T::mma(ad, vf[b][s], DP[b]); }
+          nl[4 * gq] = l4.x; nl[4 * gq + 1] = l4.y; nl[4 * gq + 2] = l4.z; nl[4 * gq + 3] = l4.w;
+          dl[4 * gq] = d4.x; dl[4 * gq + 1] = d4.y; dl[4 * gq + 2] = d4.z; dl[4 * gq + 3] = d4.w;
         }
         if (full) {
 #pragma unroll
           for (int b = 0; b < KB; ++b)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-              const float pv = fast_exp2(S[b][g] * c);
+              const float pv = fast_exp2(__builtin_fmaf(S[b][g], c, -nl[g]));
               S[b][g] = pv;
-              DP[b][g] = pv * DP[b][g] * p.scale;
+              DP[b][g] = pv * (DP[b][g] - dl[g]);
             }
         } else {
 #pragma unroll
@@ -602,9 +642,9 @@ __global__ __launch_bounds__(256 * NG) void tree_attn_bwd_dkv_kernel(AttnParams 
             for (int g = 0; g < 16; ++g) {
               const int qi = qi0 + 32 * qb + 8 * (g >> 2) + 4 * h + (g & 3);
               const bool ok = (kidx[b] <= qi) && (qi < se_l[b]);
-              const float pv = ok ? fast_exp2(S[b][g] * c) : 0.f;
+              const float pv = ok ? fast_exp2(__builtin_fmaf(S[b][g], c, -nl[g])) : 0.f;
               S[b][g] = pv;
-              DP[b][g] = pv * DP[b][g] * p.scale;
+              DP[b][g] = pv * (DP[b][g] - dl[g]);
             }
         }
 #pragma unroll
@@ -614,8 +654,8 @@ __global__ __launch_bounds__(256 * NG) void tree_attn_bwd_dkv_kernel(AttnParams 
           for (int b = 0; b < KB; ++b) { pb[b] = pack_half<DT>(S[b], s2); sb[b] = pack_half<DT>(DP[b], s2); }
 #pragma unroll
           for (int db = 0; db < 4; ++db) {
-            const v8 adt = tr_frag<v8>(Ds, 32 * qb + 16 * s2, db, lane);
-            const v8 aqt = tr_frag<v8>(Qs, 32 * qb + 16 * s2, db, lane);
+            const v8 adt = tr_pair<v8>(smem + at[db] + TILE_BYTES + 4096 * s2, smem + at[4 + db] + TILE_BYTES + 4096 * s2);
+            const v8 aqt = tr_pair<v8>(smem + at[db] + 4096 * s2, smem + at[4 + db] + 4096 * s2);
 #pragma unroll
             for (int b = 0; b < KB; ++b) { DV[b][db] = T::mma(adt, pb[b], DV[b][db]); DK[b][db] = T::mma(aqt, sb[b], DK[b][db]); }
           }
@@ -647,6 +687,12 @@ __global__ __launch_bounds__(256 * NG) void tree_attn_bwd_dkv_kernel(AttnParams 
       }
     if (grp == 1) return;
   }
+#pragma unroll
+  for (int b = 0; b < KB; ++b)
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) DK[b][db][g] *= p.scale;
 #pragma unroll
   for (int b = 0; b < KB; ++b) {
     const int kloc = wave * 32 * KB + 32 * b + r;
