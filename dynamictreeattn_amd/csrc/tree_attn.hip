@@ -100,7 +100,8 @@ struct TileIter {
   int diag_first_q;                     // NULL-run mode: packed index of the tile's first query
   __device__ __forceinline__ bool load_run() {
     while (ri < re) {
-      k0 = runs[4 * ri]; kend = runs[4 * ri + 1]; flag = runs[4 * ri + 2];
+      k0 = __builtin_amdgcn_readfirstlane(runs[4 * ri]); kend = __builtin_amdgcn_readfirstlane(runs[4 * ri + 1]);
+      flag = __builtin_amdgcn_readfirstlane(runs[4 * ri + 2]);       // workgroup-uniform: keep the cursor in SGPRs
       if (k0 < kend) return true;
       ++ri;
     }
@@ -185,20 +186,45 @@ template <class V8> __device__ __forceinline__ V8 tr_frag_o(const char* img_r0, 
 }
 
 // K/V tile pair global -> LDS by LDS-DMA: NW waves move the 16 + 16 one-KiB pieces (4 image rows each) of the
-// two 64-row images; the image's XOR swizzle goes on the per-lane SOURCE chunk.  subtree_end of the 64 keys
-// takes the ordinary path first (an ordinary load issued behind a DMA would drain it).
-#define DTA_KV_DMA(BASE, K0, KEND, NW)                                                                     \
-  { char* base_ = (BASE);                                                                                  \
-    if (tid < 64) { const int ki_ = (K0) + tid;                                                            \
-      reinterpret_cast<int*>(base_ + 2 * TILE_BYTES)[tid] = (ki_ < (KEND)) ? (p.subtree_end ? p.subtree_end[ki_] : 0x7fffffff) : 0; } \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) {                                             \
-      const int piece_ = wave * (16 / (NW)) + i_, row_ = 4 * piece_ + (lane >> 4);                         \
-      const int ch_ = (lane & 15) ^ (((row_ & 3) << 2) | ((row_ >> 2) & 3));                                \
-      int kr_ = (K0) + row_; kr_ = kr_ < p.Tk ? kr_ : p.Tk - 1;                                            \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (int64_t)kr_ * p.kv_st + ch_ * 8), \
-                                       (__attribute__((address_space(3))) void*)(base_ + piece_ * 1024), 16, 0, 0);               \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (int64_t)kr_ * p.v_st + ch_ * 8),  \
-                                       (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + piece_ * 1024), 16, 0, 0); } }
+// two 64-row images; the image's XOR swizzle goes on the per-lane SOURCE chunk.  Per-lane source offsets
+// (voff_k / voff_v, bytes inside a 64-row tile) are fixed for the whole sweep, so per tile only a scalar base
+// moves (scalar-base + lane-offset DMA form).  subtree_end of the 64 keys goes by 4-byte DMA from wave 0 (an
+// ordinary load + ds_write would park that wave for a memory latency on every tile); keys at or beyond the
+// run end are excluded by the caller's `k <= min(q, kend-1)` test, not by a sentinel.
+#define DTA_KV_OFFSETS(NW)                                                                                 \
+  uint32_t voff_k[16 / (NW)], voff_v[16 / (NW)];                                                           \
+  _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) {                                               \
+    const int piece_ = wave * (16 / (NW)) + i_, row_ = 4 * piece_ + (lane >> 4);                           \
+    const int ch_ = (lane & 15) ^ (((row_ & 3) << 2) | ((row_ >> 2) & 3));                                  \
+    voff_k[i_] = (uint32_t)((row_ * p.kv_st + ch_ * 8) * (int64_t)sizeof(e));                              \
+    voff_v[i_] = (uint32_t)((row_ * p.v_st + ch_ * 8) * (int64_t)sizeof(e)); }
+#define DTA_KV_DMA(BASE, K0, NW)                                                                           \
+  { char* base_ = (BASE); const int k0_ = (K0);                                                            \
+    if (wave == 0) {                                                                                       \
+      if (p.subtree_end) { int ki_ = k0_ + lane; ki_ = ki_ < p.Tk ? ki_ : p.Tk - 1;                        \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.subtree_end + ki_), \
+                                         (__attribute__((address_space(3))) void*)(base_ + 2 * TILE_BYTES), 4, 0, 0); } \
+      else reinterpret_cast<int*>(base_ + 2 * TILE_BYTES)[lane] = 0x7fffffff; }                            \
+    const char* kb_ = reinterpret_cast<const char*>(kbase) + (int64_t)k0_ * p.kv_st * (int64_t)sizeof(e);  \
+    const char* vb_ = reinterpret_cast<const char*>(vbase) + (int64_t)k0_ * p.v_st * (int64_t)sizeof(e);   \
+    if (k0_ + 64 <= p.Tk) {                                                                                \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) {                                           \
+        const int piece_ = wave * (16 / (NW)) + i_;                                                        \
+        uint32_t ok_ = voff_k[i_], ov_ = voff_v[i_];                                                       \
+        asm volatile("" : "+v"(ok_), "+v"(ov_));   /* keeps the 32->64-bit extension next to the DMA: scalar-base form */ \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb_ + ok_),       \
+                                         (__attribute__((address_space(3))) void*)(base_ + piece_ * 1024), 16, 0, 0);               \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb_ + ov_),       \
+                                         (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + piece_ * 1024), 16, 0, 0); } \
+    } else {                                       /* ragged last tile of the tensor: clamp the row per lane */ \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) {                                           \
+        const int piece_ = wave * (16 / (NW)) + i_, row_ = 4 * piece_ + (lane >> 4);                       \
+        const int ch_ = (lane & 15) ^ (((row_ & 3) << 2) | ((row_ >> 2) & 3));                              \
+        const int rr_ = k0_ + row_ < p.Tk ? row_ : p.Tk - 1 - k0_;                                         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb_ + ((int64_t)rr_ * p.kv_st + ch_ * 8) * (int64_t)sizeof(e)), \
+                                         (__attribute__((address_space(3))) void*)(base_ + piece_ * 1024), 16, 0, 0);               \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb_ + ((int64_t)rr_ * p.v_st + ch_ * 8) * (int64_t)sizeof(e)),  \
+                                         (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + piece_ * 1024), 16, 0, 0); } } }
 
 // =================================================================================================
 // forward.  HPB = query heads of one kv group handled by a workgroup (waves 4*hb .. 4*hb+3 own head hb);
@@ -211,7 +237,8 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
   constexpr int NW = 4 * HPB, BUF = 2 * TILE_BYTES + SE_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[QK_LDS];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform values live in SGPRs
   const int hb = wave >> 2, rw = wave & 3;
   const int bid = blockIdx.x;
   const int hgroups = p.group / HPB;
@@ -236,6 +263,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
   const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
   const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.v_sh;
   const FragOffs offs = frag_offsets(lane);
+  DTA_KV_OFFSETS(NW)
 
   f32x16 O[4];
 #pragma unroll
@@ -245,16 +273,16 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
   float m = -1e30f, lsum = 0.f;
   const float c = p.scale * LOG2E;
 
-  int ck0 = it.k0; bool cmask = it.masked();
-  DTA_KV_DMA(smem, it.k0, it.kend, NW)
+  int ck0 = it.k0, ckend = it.kend; bool cmask = it.masked();
+  DTA_KV_DMA(smem, it.k0, NW)
   bool has_next = it.advance();
   __syncthreads();                                                 // hipcc drains the DMA (vmcnt(0)) in front of the barrier
 
   // one tile out of buffer BUFI (compile-time): prefetch the next tile into the other buffer, S^T, softmax, PV
 #define FWD_TILE(BUFI)                                                                                     \
   {                                                                                                        \
-    int nk0_ = 0; bool nmask_ = false;                                                                     \
-    if (has_next) { nk0_ = it.k0; nmask_ = it.masked(); DTA_KV_DMA(smem + (1 - (BUFI)) * BUF, it.k0, it.kend, NW) } \
+    int nk0_ = 0, nkend_ = 0; bool nmask_ = false;                                                         \
+    if (has_next) { nk0_ = it.k0; nkend_ = it.kend; nmask_ = it.masked(); DTA_KV_DMA(smem + (1 - (BUFI)) * BUF, it.k0, NW) } \
     const char* Ks = smem + (BUFI) * BUF; const char* Vs = Ks + TILE_BYTES;                                \
     const int* se_s = reinterpret_cast<const int*>(Ks + 2 * TILE_BYTES);                                   \
     f32x16 X[2];                                                                                           \
@@ -264,13 +292,14 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
         X[kb] = T::mma(DTA_ABL_A(*reinterpret_cast<const v8*>(Ks + 8192 * kb + offs.row[s]), qf[(s + 1) & 7]), qf[s], X[kb]); \
     }                                                                                                      \
     if (cmask) {                                                                                           \
+      const int qlim = qidx < ckend ? qidx : ckend - 1;      /* keys at or beyond the run end never count */ \
       _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                     \
         _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                 \
           const int kl = 32 * kb + 8 * gq + 4 * h;                                                         \
           const int4 se4 = *reinterpret_cast<const int4*>(se_s + kl);                                      \
           const int sev[4] = {se4.x, se4.y, se4.z, se4.w};                                                 \
           _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
-            const bool ok = (ck0 + kl + j <= qidx) && (qidx < sev[j]);                                     \
+            const bool ok = (ck0 + kl + j <= qlim) && (qidx < sev[j]);                                     \
             X[kb][4 * gq + j] = ok ? X[kb][4 * gq + j] : -INFINITY;                                        \
           }                                                                                                \
         }                                                                                                  \
@@ -296,7 +325,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
     }                                                                                                      \
     if (!(DTA_ABL & 8)) __syncthreads();                                                                   \
     if (!has_next) break;                                                                                  \
-    ck0 = nk0_; cmask = nmask_;                                                                            \
+    ck0 = nk0_; ckend = nkend_; cmask = nmask_;                                                            \
     has_next = it.advance();                                                                               \
   }
   while (true) {
@@ -561,9 +590,11 @@ __global__ __launch_bounds__(256 * NG) void tree_attn_bwd_dkv_kernel(AttnParams 
     const char* db_ = reinterpret_cast<const char*>(p.dout) + ((int64_t)hq_ * p.o_sh + (int64_t)row0_ * p.o_st) * (int64_t)sizeof(e); \
     if (row0_ + 64 <= p.Tq) {                                                                              \
       _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb_ + voff_q[i_]), \
+        uint32_t oq_ = voff_q[i_], od_ = voff_d[i_];                                                       \
+        asm volatile("" : "+v"(oq_), "+v"(od_));   /* keeps the 32->64-bit extension next to the DMA: scalar-base form */ \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb_ + oq_),       \
                                          (__attribute__((address_space(3))) void*)(base_ + (wave * 4 + i_) * 1024), 16, 0, 0);              \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + voff_d[i_]), \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + od_),       \
                                          (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + (wave * 4 + i_) * 1024), 16, 0, 0); } \
     } else {                                       /* ragged last tile of the tensor: clamp the row per lane */ \
       _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
