@@ -152,7 +152,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 #define DTA_ABL_E(real, fake) ((DTA_ABL & 1) ? (fake) : (real))
 #define DTA_ABL_A(real, fake) ((DTA_ABL & 2) ? (fake) : (real))
 #define DTA_ABL_B(real, fake) ((DTA_ABL & 4) ? (fake) : (real))
-// 8 = no per-tile barrier in the forward (races: timing only)
+// 8 = no per-tile barrier in the forward (races: timing only); 16 = forward with one head per workgroup (valid results)
 
 // Per-lane byte offsets of every fragment read inside one image, computed once: the XOR swizzle depends on the
 // lane only (row blocks of 32 and k-steps of 16 rows leave row&3 and (row>>2)&3 unchanged), so inside the tile
@@ -806,7 +806,7 @@ extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v,
   const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   (void)hipGetLastError();   // drop a stale error of an earlier, unrelated runtime call
-  if (p.group % 2 == 0) {      // two query heads of a kv group share the staged K/V tiles
+  if (p.group % 2 == 0 && !(DTA_ABL & 16)) {      // two query heads of a kv group share the staged K/V tiles
     dim3 grid(nqt * Hq / 2), block(512);
     if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_BF16, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_F16, 2>), grid, block, 0, st, p);

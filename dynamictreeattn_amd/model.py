@@ -120,25 +120,25 @@ def _layer_forward(layer, res, delta, cos_sin, meta, Hq, Hkv, D, eps):
     if FUSE_PROJECTIONS:
         # one projection GEMM for q,k,v (and one for gate,up below): the weights stay separate parameters with
         # their HF names; stacking them is three plain copies whose backward hands out gradient row slices
-        qkv = F.linear(h, ops.stack_rows(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight),
+        qkv = ops.linear(h, ops.stack_rows(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight),
                        torch.cat([bq, bk, bv]) if bq is not None else None).view(T, Hq + 2 * Hkv, D)
         q, k, v = qkv.split([Hq, Hkv, Hkv], dim=1)            # split's backward is ONE concatenation
     else:
-        q = F.linear(h, a.q_proj.weight, bq).view(T, Hq, D)
-        k = F.linear(h, a.k_proj.weight, bk).view(T, Hkv, D)
-        v = F.linear(h, a.v_proj.weight, bv).view(T, Hkv, D)
+        q = ops.linear(h, a.q_proj.weight, bq).view(T, Hq, D)
+        k = ops.linear(h, a.k_proj.weight, bk).view(T, Hkv, D)
+        v = ops.linear(h, a.v_proj.weight, bv).view(T, Hkv, D)
     qn = getattr(a, "q_norm", None); kn = getattr(a, "k_norm", None)
     q = ops.qk_norm_rope(q, qn.weight if qn is not None else None, cos_sin, eps)
     k = ops.qk_norm_rope(k, kn.weight if kn is not None else None, cos_sin, eps)
     o = ops.tree_attention(q, k, v, meta)
-    attn_out = F.linear(o.reshape(T, Hq * D), a.o_proj.weight)
+    attn_out = ops.linear(o.reshape(T, Hq * D), a.o_proj.weight)
     res, h = ops.add_rms_norm(res, attn_out, layer.post_attention_layernorm.weight, eps)
     m = layer.mlp
     if FUSE_PROJECTIONS:
-        act = ops.swiglu_fused(F.linear(h, ops.stack_rows(m.gate_proj.weight, m.up_proj.weight)))
+        act = ops.swiglu_fused(ops.linear(h, ops.stack_rows(m.gate_proj.weight, m.up_proj.weight)))
     else:
-        act = ops.swiglu(F.linear(h, m.gate_proj.weight), F.linear(h, m.up_proj.weight))
-    return res, F.linear(act, m.down_proj.weight)
+        act = ops.swiglu(ops.linear(h, m.gate_proj.weight), ops.linear(h, m.up_proj.weight))
+    return res, ops.linear(act, m.down_proj.weight)
 
 
 def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta, checkpoint_layers: bool = False) -> torch.Tensor:

@@ -89,6 +89,31 @@ def plan_segments(lens: Sequence[int], lcp_lens: Sequence[int]) -> SegmentPlan:
                        np.asarray(ptr, np.int32), np.asarray(bd, np.int32), np.asarray(be, np.int32), path_runs)
 
 
+def pad_plan(plan: SegmentPlan, multiple: int = 256) -> SegmentPlan:
+    """Append one detached chain of filler tokens (depths 0.., no ancestors, no descendants, in no leaf's path) so
+    that the packed length is a multiple of `multiple`: hipBLASLt's projection GEMMs lose 5-15 % on a ragged row
+    count (scripts/gemm_shapes.py).  Real tokens are untouched — no real token's subtree reaches past the old T —
+    and the filler rows receive zero gradient.  `n_real` keeps the number of real segments."""
+    pad = (-plan.T) % multiple
+    if pad == 0:
+        out = SegmentPlan(plan.M, plan.T, plan.seg_off, plan.seg_depth0, plan.parent_of_seg, plan.brk_ptr, plan.brk_depth,
+                          plan.brk_end, plan.path_runs)
+        out.n_real = plan.M
+        return out
+    T2 = plan.T + pad
+    i32 = np.int32
+    out = SegmentPlan(plan.M + 1, T2,
+                      np.concatenate([plan.seg_off, np.asarray([T2], i32)]),
+                      np.concatenate([plan.seg_depth0, np.asarray([0], i32)]),
+                      np.concatenate([plan.parent_of_seg, np.asarray([-1], i32)]),
+                      np.concatenate([plan.brk_ptr, np.asarray([plan.brk_ptr[-1] + 1], i32)]),
+                      np.concatenate([plan.brk_depth, np.asarray([0], i32)]),
+                      np.concatenate([plan.brk_end, np.asarray([T2], i32)]),
+                      plan.path_runs + [[]])
+    out.n_real = plan.M
+    return out
+
+
 def expand_plan_host(plan: SegmentPlan):
     """numpy mirror of dta_preorder_meta's index arithmetic (tests and CPU-side planning checks only;
     the engine uses the HIP kernel).  Returns (seg_of_token, depth, parent, subtree_end)."""

@@ -92,11 +92,21 @@ def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tenso
 class _PackedTrie:
     """Device-resident packed form of a TokenTrie (in its current leaf order)."""
 
+    PAD_FROM = int(__import__("os").environ.get("DTA_PAD_FROM", 2048))   # packed lengths from here on are rounded up to PAD_TO rows of filler (packing.pad_plan); env = diagnostic A/B switch
+    PAD_TO = 256
+
     def __init__(self, trie, device, n_kv_heads: int = 8):
-        self.plan = plan = packing.plan_segments(trie.lens, trie.lcp_lens)
+        plan = packing.plan_segments(trie.lens, trie.lcp_lens)
+        self.n_real_tokens = plan.T
+        M_real = plan.M
+        leaf_off = [trie._dev.starts[s] for s in trie._leaf_src]
+        if plan.T >= self.PAD_FROM and plan.T % self.PAD_TO:
+            plan = packing.pad_plan(plan, self.PAD_TO)       # filler ids are read from the head of the token buffer
+            leaf_off = leaf_off + [0]
+        self.plan = plan
         M, T = plan.M, plan.T
         run_ptr, runs = packing.plan_qtile_runs(plan)
-        leaf_off = np.asarray([trie._dev.starts[s] for s in trie._leaf_src], np.int64)
+        leaf_off = np.asarray(leaf_off, np.int64)
         parts = [plan.seg_off, plan.seg_depth0, plan.parent_of_seg, plan.brk_ptr, plan.brk_depth, plan.brk_end,
                  run_ptr, runs.reshape(-1)]
         sizes = [p.size for p in parts]
@@ -122,7 +132,7 @@ class _PackedTrie:
         self.fork_child, self.fork_parent = first[is_fork], par[is_fork]
         # root path of every leaf as packed indices (depth 0 .. len-1)
         paths = []
-        for i in range(M):
+        for i in range(M_real):
             pieces = [np.arange(b, e, dtype=np.int64) for b, e in plan.path_runs[i]]
             pieces.append(np.arange(plan.seg_off[i], plan.seg_off[i + 1], dtype=np.int64))
             paths.append(np.concatenate(pieces))

@@ -140,6 +140,51 @@ def test_packing_plan_matches_bruteforce():
             assert need <= cov
 
 
+def test_padded_plan_keeps_real_tokens_and_isolates_filler():
+    for case in synth.trie_cases()[:12]:
+        seqs = synth.make_case(case)
+        if sum(map(len, seqs)) > 3000:
+            continue
+        t = TokenTrie(synth.as_tensors(seqs), device=CPU); t.backward_permute()
+        plan = packing.plan_segments(t.lens, t.lcp_lens)
+        for mult in (16, 64):
+            pp = packing.pad_plan(plan, mult)
+            assert pp.T % mult == 0 and pp.T - plan.T < mult and pp.n_real == plan.M
+            _, d0, p0, s0 = hostmirror.expand_plan_host(plan)
+            _, d1, p1, s1 = hostmirror.expand_plan_host(pp)
+            T = plan.T
+            assert d1[:T].tolist() == d0.tolist() and p1[:T].tolist() == p0.tolist() and s1[:T].tolist() == s0.tolist()
+            assert int(s0.max(initial=0)) <= T                                   # no real subtree reaches the filler
+            n = pp.T - T
+            assert d1[T:].tolist() == list(range(n)) and s1[T:].tolist() == [pp.T] * n
+            assert p1[T:].tolist() == ([-1] + list(range(T, pp.T - 1)) if n else [])
+            rp, runs = packing.plan_qtile_runs(pp, 16)
+            for qt in range(len(rp) - 1):                                       # filler rows only ever meet filler keys
+                for b, e, f, _ in runs[rp[qt]:rp[qt + 1]]:
+                    if qt * 16 >= T:
+                        assert b >= T
+                    if e > T and b < T:
+                        assert f == 1
+
+
+def test_engine_padding_changes_nothing(monkeypatch):
+    from dynamictreeattn_amd import tree_training_engine as tte
+    m, seqs = _model("d128_minitau")
+    outs = []
+    for pad_from in (1 << 30, 1):
+        monkeypatch.setattr(tte._PackedTrie, "PAD_FROM", pad_from)
+        monkeypatch.setattr(tte._PackedTrie, "PAD_TO", 64)
+        m.zero_grad(set_to_none=True)
+        t = TokenTrie(seqs, _att(len(seqs)), device=CPU); t.backward_permute()
+        eng = tte.TreeTrainingEngine(m.config, CPU, torch.float32, 4096)
+        loss = eng.backward(m, t, mo.default_loss, 2048)
+        assert (eng.last_packed.plan.T % 64 == 0) == (pad_from == 1) or eng.last_packed.n_real_tokens % 64 == 0
+        outs.append((float(loss), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-5 * abs(outs[0][0])
+    for k in outs[0][1]:
+        assert mo.grad_ratio(outs[1][1][k], outs[0][1][k]) < 1e-5, k
+
+
 @pytest.fixture(scope="module")
 def eng_gold():
     return torch.load(os.path.join(GOLD, "engine_tiny.pt"), weights_only=True)
