@@ -27,7 +27,7 @@ _PROTOS = {
     "dta_rmsnorm_bwd": ([_vp] * 7 + [_i32, _i32, _i32, _vp], C.c_int),
     "dta_qk_norm_rope_fwd": ([_vp] * 5 + [_i32, _i32, _i32, _i64, _f32, _i32, _vp], C.c_int),
     "dta_qk_norm_rope_bwd_blocks": ([_i64], C.c_int),
-    "dta_qk_norm_rope_bwd": ([_vp] * 7 + [_i32, _i32, _i32, _i64, _i64, _i64, _i32, _vp], C.c_int),
+    "dta_qk_norm_rope_bwd": ([_vp] * 7 + [_i32, _i32, _i32, _i64, _i64, _i64, _i64, _i32, _vp], C.c_int),
     "dta_swiglu_fwd": ([_vp] * 3 + [_i64, _i32, _i64, _i32, _vp], C.c_int),
     "dta_swiglu_bwd": ([_vp] * 5 + [_i64, _i32, _i64, _i64, _i32, _vp], C.c_int),
 }

@@ -192,7 +192,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_, const float* __restrict__ cs,
                                                                const void* __restrict__ dy_, const float* __restrict__ rstd,
                                                                void* __restrict__ dx_, float* __restrict__ dw_part, int64_t n_heads_total, int NH,
-                                                               int64_t x_st, int64_t dy_st_t, int64_t dy_st_h) {
+                                                               int64_t x_st, int64_t dy_st_t, int64_t dy_st_h, int64_t dx_st) {
   using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
   __shared__ float red[256 * 8];
   const int lane = threadIdx.x & 63, sub = lane & 15;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const void* __res
       const float cj = c[j], sj = c[64 + j];
       da[j] = sub < 8 ? gj * cj + other * sj : gj * cj - other * sj;
     }
-    e* dx = reinterpret_cast<e*>(dx_) + hc * 128 + 8 * sub;
+    e* dx = reinterpret_cast<e*>(dx_) + tok * dx_st + (int64_t)head * 128 + 8 * sub;
     v8 o;
     if (w_) {
       const e* x = reinterpret_cast<const e*>(x_) + tok * x_st + (int64_t)head * 128 + 8 * sub;
@@ -330,12 +330,13 @@ extern "C" int dta_qk_norm_rope_fwd(const void* x, const void* w, const float* c
 extern "C" int dta_qk_norm_rope_bwd_blocks(int64_t n_heads_total) { return row_blocks(n_heads_total, 16, 1024); }
 extern "C" int dta_qk_norm_rope_bwd(const void* x, const void* w, const float* cos_sin, const void* dy, const float* rstd,
                                     void* dx, float* dw_partial, int32_t T, int32_t NH, int32_t head_dim,
-                                    int64_t x_stride_t, int64_t dy_stride_t, int64_t dy_stride_h, int32_t dtype, void* stream) {
+                                    int64_t x_stride_t, int64_t dy_stride_t, int64_t dy_stride_h, int64_t dx_stride_t, int32_t dtype, void* stream) {
   if (!cos_sin || !dy || !dx || T <= 0 || NH <= 0 || (w && (!x || !rstd || !dw_partial))) return DTA_EINVAL;
   if ((dtype != DTA_BF16 && dtype != DTA_F16) || head_dim != 128) return DTA_EUNSUPPORTED;
-  if (!al16(dy) || !al16(dx) || (w && (!al16(w) || !al16(x))) || x_stride_t % 8 || dy_stride_t % 8 || dy_stride_h % 8) return DTA_EALIGN;
+  if (!al16(dy) || !al16(dx) || (w && (!al16(w) || !al16(x))) || x_stride_t % 8 || dy_stride_t % 8 || dy_stride_h % 8 || dx_stride_t % 8) return DTA_EALIGN;
+  if (dx_stride_t < (int64_t)NH * 128) return DTA_EINVAL;
   const int64_t n = (int64_t)T * NH;
-  DTA_DISPATCH(qk_norm_rope_bwd_kernel, row_blocks(n, 16, 1024), x, w, cos_sin, dy, rstd, dx, dw_partial, n, NH, x_stride_t, dy_stride_t, dy_stride_h);
+  DTA_DISPATCH(qk_norm_rope_bwd_kernel, row_blocks(n, 16, 1024), x, w, cos_sin, dy, rstd, dx, dw_partial, n, NH, x_stride_t, dy_stride_t, dy_stride_h, dx_stride_t);
 }
 
 extern "C" int dta_swiglu_fwd(const void* gate, const void* up, void* y, int64_t rows, int32_t cols, int64_t ld, int32_t dtype, void* stream) {

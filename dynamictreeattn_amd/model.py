@@ -122,14 +122,15 @@ def _layer_forward(layer, res, delta, cos_sin, meta, Hq, Hkv, D, eps):
         # their HF names; stacking them is three plain copies whose backward hands out gradient row slices
         qkv = ops.linear(h, ops.stack_rows(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight),
                        torch.cat([bq, bk, bv]) if bq is not None else None).view(T, Hq + 2 * Hkv, D)
-        q, k, v = qkv.split([Hq, Hkv, Hkv], dim=1)            # split's backward is ONE concatenation
+        qn = getattr(a, "q_norm", None); kn = getattr(a, "k_norm", None)
+        q, k, v = ops.qkv_prep(qkv, qn.weight if qn is not None else None, kn.weight if kn is not None else None, cos_sin, eps, Hq, Hkv)
     else:
         q = ops.linear(h, a.q_proj.weight, bq).view(T, Hq, D)
         k = ops.linear(h, a.k_proj.weight, bk).view(T, Hkv, D)
         v = ops.linear(h, a.v_proj.weight, bv).view(T, Hkv, D)
-    qn = getattr(a, "q_norm", None); kn = getattr(a, "k_norm", None)
-    q = ops.qk_norm_rope(q, qn.weight if qn is not None else None, cos_sin, eps)
-    k = ops.qk_norm_rope(k, kn.weight if kn is not None else None, cos_sin, eps)
+        qn = getattr(a, "q_norm", None); kn = getattr(a, "k_norm", None)
+        q = ops.qk_norm_rope(q, qn.weight if qn is not None else None, cos_sin, eps)
+        k = ops.qk_norm_rope(k, kn.weight if kn is not None else None, cos_sin, eps)
     o = ops.tree_attention(q, k, v, meta)
     attn_out = ops.linear(o.reshape(T, Hq * D), a.o_proj.weight)
     res, h = ops.add_rms_norm(res, attn_out, layer.post_attention_layernorm.weight, eps)

@@ -394,9 +394,57 @@ class _QKNormRope(torch.autograd.Function):
         if ctx.has_w:
             part = torch.empty(lib().dta_qk_norm_rope_bwd_blocks(T * NH), D, dtype=torch.float32, device=x.device)
         check(lib().dta_qk_norm_rope_bwd(ptr(x), ptr(w) if ctx.has_w else None, ptr(cos_sin), ptr(dy), ptr(rstd) if ctx.has_w else None,
-                                         ptr(dx), ptr(part), T, NH, D, x.stride(0), dy.stride(0), dy.stride(1), _DT[x.dtype], _stream()),
+                                         ptr(dx), ptr(part), T, NH, D, x.stride(0), dy.stride(0), dy.stride(1), dx.stride(0), _DT[x.dtype], _stream()),
               "dta_qk_norm_rope_bwd")
         return dx, (part.sum(0).to(w.dtype) if ctx.has_w else None), None, None
+
+
+class _QKVPrep(torch.autograd.Function):
+    """Fused projection output qkv [T, Hq+2Hkv, D] -> (RoPE(norm(q)), RoPE(norm(k)), v).  q and k are read in place
+    from the fused buffer (token stride) and v is returned as a view of it; the backward writes the three
+    gradients straight into ONE [T, Hq+2Hkv, D] buffer (the rope kernels take an output token stride), so
+    the 200 MB concatenation that `split`'s backward would do per layer disappears."""
+
+    @staticmethod
+    def forward(ctx, qkv, wq, wk, cos_sin, eps, Hq, Hkv):
+        _require_cuda(qkv, cos_sin)
+        T, H3, D = qkv.shape
+        assert H3 == Hq + 2 * Hkv and qkv.is_contiguous()
+        outs, rstds = [], []
+        for x, w, NH in ((qkv[:, :Hq], wq, Hq), (qkv[:, Hq:Hq + Hkv], wk, Hkv)):
+            y = torch.empty((T, NH, D), dtype=qkv.dtype, device=qkv.device)
+            rstd = torch.empty(T * NH, dtype=torch.float32, device=qkv.device) if w is not None else None
+            check(lib().dta_qk_norm_rope_fwd(ptr(x), ptr(w), ptr(cos_sin), ptr(y), ptr(rstd), T, NH, D, qkv.stride(0), float(eps),
+                                             _DT[qkv.dtype], _stream()), "dta_qk_norm_rope_fwd")
+            outs.append(y); rstds.append(rstd if rstd is not None else cos_sin)
+        ctx.save_for_backward(qkv, wq if wq is not None else cos_sin, wk if wk is not None else cos_sin, cos_sin, rstds[0], rstds[1])
+        ctx.has_w = (wq is not None, wk is not None)
+        ctx.heads = (Hq, Hkv)
+        return outs[0], outs[1], qkv[:, Hq + Hkv:]
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        qkv, wq, wk, cos_sin, rq, rk = ctx.saved_tensors
+        Hq, Hkv = ctx.heads
+        T, H3, D = qkv.shape
+        d = torch.empty_like(qkv)
+        dws = []
+        for lo, NH, w, rstd, has_w, dy in ((0, Hq, wq, rq, ctx.has_w[0], dq), (Hq, Hkv, wk, rk, ctx.has_w[1], dk)):
+            if dy.stride(2) != 1:
+                dy = dy.contiguous()
+            part = torch.empty(lib().dta_qk_norm_rope_bwd_blocks(T * NH), D, dtype=torch.float32, device=qkv.device) if has_w else None
+            check(lib().dta_qk_norm_rope_bwd(ptr(qkv[:, lo:lo + NH]), ptr(w) if has_w else None, ptr(cos_sin), ptr(dy), ptr(rstd) if has_w else None,
+                                             ptr(d[:, lo:lo + NH]), ptr(part), T, NH, D, qkv.stride(0), dy.stride(0), dy.stride(1), d.stride(0),
+                                             _DT[qkv.dtype], _stream()), "dta_qk_norm_rope_bwd")
+            dws.append(part.sum(0).to(w.dtype) if has_w else None)
+        d[:, Hq + Hkv:].copy_(dv)
+        return d, dws[0], dws[1], None, None, None, None
+
+
+def qkv_prep(qkv: torch.Tensor, wq: Optional[torch.Tensor], wk: Optional[torch.Tensor], cos_sin: torch.Tensor, eps: float,
+             Hq: int, Hkv: int):
+    """(q, k, v) for `tree_attention` from the fused projection output [T, Hq+2Hkv, 128]."""
+    return _QKVPrep.apply(qkv, wq, wk, cos_sin, eps, Hq, Hkv)
 
 
 def qk_norm_rope(x: torch.Tensor, w: Optional[torch.Tensor], cos_sin: torch.Tensor, eps: float) -> torch.Tensor:

@@ -85,6 +85,11 @@ def _cpu_qk_norm_rope(x, w, cos_sin, eps):
     return x * cos + torch.cat([-x[..., half:], x[..., :half]], -1) * sin
 
 
+def _cpu_qkv_prep(qkv, wq, wk, cos_sin, eps, Hq, Hkv):
+    q, k, v = qkv.split([Hq, Hkv, Hkv], dim=1)
+    return _cpu_qk_norm_rope(q, wq, cos_sin, eps), _cpu_qk_norm_rope(k, wk, cos_sin, eps), v
+
+
 def _cpu_swiglu(g, u):
     return torch.nn.functional.silu(g) * u
 
@@ -103,5 +108,6 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "rms_norm", _cpu_rms_norm)
     monkeypatch.setattr(ops, "add_rms_norm", _cpu_add_rms_norm)
     monkeypatch.setattr(ops, "qk_norm_rope", _cpu_qk_norm_rope)
+    monkeypatch.setattr(ops, "qkv_prep", _cpu_qkv_prep)
     monkeypatch.setattr(ops, "swiglu", _cpu_swiglu)
     monkeypatch.setattr(ops, "swiglu_fused", _cpu_swiglu_fused)

@@ -36,7 +36,7 @@ def _dp_worker(rank, world, port, name, q):
     token_trie._device_trie_arrays = hostmirror._cpu_trie_arrays
     tree_training_engine._PackedTrie._expand = hostmirror._cpu_expand
     for k, fn in {"tree_attention": "_cpu_attention", "lm_head_rows": "_cpu_lm_head_rows", "rms_norm": "_cpu_rms_norm", "add_rms_norm": "_cpu_add_rms_norm",
-                  "qk_norm_rope": "_cpu_qk_norm_rope", "swiglu": "_cpu_swiglu", "swiglu_fused": "_cpu_swiglu_fused"}.items():
+                  "qk_norm_rope": "_cpu_qk_norm_rope", "qkv_prep": "_cpu_qkv_prep", "swiglu": "_cpu_swiglu", "swiglu_fused": "_cpu_swiglu_fused"}.items():
         setattr(ops, k, getattr(hostmirror, fn))
     _orig = token_trie.TokenTrie.__init__
     token_trie.TokenTrie.__init__ = lambda self, *a, **kw: _orig(self, *a, **{**kw, "device": torch.device("cpu")})

@@ -57,6 +57,22 @@ def test_qk_norm_rope(T, NH, norm, dtype):
         _pair(lambda a: ops.qk_norm_rope(a, None, cs.to(DEV), 1e-6), ref, [x], dtype)
 
 
+@pytest.mark.parametrize("T,Hq,Hkv,norm,dtype", [(1, 2, 1, True, torch.bfloat16), (300, 16, 8, True, torch.bfloat16), (129, 4, 4, False, torch.float16)])
+def test_qkv_prep_fused_buffer(T, Hq, Hkv, norm, dtype):
+    """q/k read in place from the fused projection output, v a view of it, ONE gradient buffer in the backward."""
+    g = torch.Generator().manual_seed(T + Hq)
+    qkv = torch.randn(T, Hq + 2 * Hkv, 128, generator=g)
+    wq = (1 + 0.2 * torch.randn(128, generator=g)) if norm else None
+    wk = (1 + 0.2 * torch.randn(128, generator=g)) if norm else None
+    cs = ops.rope_cos_sin(torch.randint(0, 16384, (T,), generator=g), 128, 1e6)
+    def glue(fn, csx):
+        def f(a, *w):
+            q, k, v = fn(a, w[0] if w else None, w[1] if w else None, csx, 1e-6, Hq, Hkv)
+            return torch.cat([q, 2.0 * k, 0.5 * v], dim=1)
+        return f
+    _pair(glue(ops.qkv_prep, cs.to(DEV)), glue(hostmirror._cpu_qkv_prep, cs.float()), [qkv] + ([wq, wk] if norm else []), dtype)
+
+
 @pytest.mark.parametrize("shape,dtype", [((3, 8), torch.bfloat16), ((1000, 3072), torch.bfloat16), ((77, 9728), torch.float16)])
 def test_swiglu(shape, dtype):
     g = torch.Generator().manual_seed(shape[0])
