@@ -799,6 +799,8 @@ extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v,
   if ((runs == nullptr) != (run_ptr == nullptr)) return DTA_EINVAL;
   if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16)) return DTA_EUNSUPPORTED;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || (q_st | q_sh | kv_st | kv_sh | v_st | v_sh | o_st | o_sh) % 8 != 0) return DTA_EALIGN;
+  // the tile DMA addresses a 64-row tile as scalar base + 32-bit lane offset: token strides must keep 64 rows inside 4 GiB
+  if (kv_st < 0 || v_st < 0 || kv_st > (1 << 24) || v_st > (1 << 24)) return DTA_EUNSUPPORTED;
   AttnParams p{};
   p.q = q; p.k = k; p.v = v; p.out = out; p.lse_w = lse; p.subtree_end = subtree_end; p.run_ptr = run_ptr; p.runs = runs;
   p.Tq = Tq; p.Tk = Tk; p.q_offset = q_offset; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
@@ -834,6 +836,7 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16)) return DTA_EUNSUPPORTED;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) ||
       (q_st | q_sh | kv_st | kv_sh | v_st | v_sh | o_st | o_sh | dq_st | dq_sh | dkv_st | dkv_sh) % 8 != 0) return DTA_EALIGN;
+  if (q_st < 0 || o_st < 0 || q_st > (1 << 24) || o_st > (1 << 24)) return DTA_EUNSUPPORTED;   // 64-row tile = scalar base + 32-bit lane offset
   AttnParams p{};
   p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse_r = lse; p.delta = delta; p.dq = dq; p.dk = dk; p.dv = dv;
   p.subtree_end = subtree_end; p.run_ptr = run_ptr; p.runs = runs; p.ktile_qend = ktile_qend;

@@ -96,7 +96,9 @@ int dta_tree_attn_fwd(const void* q, const void* k, const void* v, void* out, fl
                       float scale, int32_t dtype, void* stream);
 
 /* General-stride form of dta_tree_attn_fwd: explicit head strides (elements) so that head-major
- * layouts such as the reference's [1, H, S, D] KV stack (tree_training_engine.py:108-131) work in place. */
+ * layouts such as the reference's [1, H, S, D] KV stack (tree_training_engine.py:108-131) work in place.
+ * Token strides of k and v (forward) and of q and dout (backward) must be in [0, 2^24] elements: a 64-row tile
+ * is addressed as scalar base + 32-bit lane offset by the tile DMA (DTA_EUNSUPPORTED otherwise). */
 int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse,
                          const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
                          int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
