@@ -764,25 +764,41 @@ __global__ __launch_bounds__(256 * NG) void tree_attn_bwd_dkv_kernel(AttnParams 
 
 // Sums the fp32 slabs of every split key tile in a fixed order and writes dK/dV (bitwise reproducible).
 // dkv_splits[s] = {key tile, first slab, number of slabs, 0}.
+constexpr int FIN_SPLIT = 8;          // blockIdx.y: each (split key tile, kv head) is summed by 8 workgroups — the sums are load-latency bound
 template <int DT>
 __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_finalize_kernel(AttnParams p) {
-  using e = typename Ty<DT>::e;
+  using e = typename Ty<DT>::e; using v4 = typename Ty<DT>::v4;
   const int KT = p.ktile;
   const int kvh = blockIdx.x % p.Hkv, sp = blockIdx.x / p.Hkv;
   const int kt = p.dkv_splits[4 * sp], first = p.dkv_splits[4 * sp + 1], n = p.dkv_splits[4 * sp + 2];
-  for (int i = threadIdx.x; i < 2 * KT * 32; i += 256) {                  // float4 index inside a slab
+  const int per = 2 * KT * 32 / FIN_SPLIT;                                // float4 indices per workgroup
+  const float* ws0 = p.dkv_ws + ((int64_t)first * p.Hkv + kvh) * (2 * KT * 128);
+  const int64_t slab_st = (int64_t)p.Hkv * (2 * KT * 128);
+  for (int i = blockIdx.y * per + threadIdx.x; i < (blockIdx.y + 1) * per; i += 256) {   // float4 index inside a slab
     const int which = i / (KT * 32), rem = i - which * KT * 32;
     const int key = rem >> 5, d = (rem & 31) << 2;
     const int kidx = kt * KT + key;
     if (kidx >= p.Tk) continue;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int j = 0; j < n; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(p.dkv_ws + ((int64_t)(first + j) * p.Hkv + kvh) * (2 * KT * 128) + (int64_t)i * 4);
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {                                          // four loads in flight, summed in slab order
+      const float4 a0 = *reinterpret_cast<const float4*>(ws0 + (j + 0) * slab_st + (int64_t)i * 4);
+      const float4 a1 = *reinterpret_cast<const float4*>(ws0 + (j + 1) * slab_st + (int64_t)i * 4);
+      const float4 a2 = *reinterpret_cast<const float4*>(ws0 + (j + 2) * slab_st + (int64_t)i * 4);
+      const float4 a3 = *reinterpret_cast<const float4*>(ws0 + (j + 3) * slab_st + (int64_t)i * 4);
+      acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+      acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w;
+      acc.x += a2.x; acc.y += a2.y; acc.z += a2.z; acc.w += a2.w;
+      acc.x += a3.x; acc.y += a3.y; acc.z += a3.z; acc.w += a3.w;
+    }
+    for (; j < n; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(ws0 + j * slab_st + (int64_t)i * 4);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     e* out = reinterpret_cast<e*>(which ? p.dv : p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh + d;
-    if (p.accumulate) { acc.x += (float)out[0]; acc.y += (float)out[1]; acc.z += (float)out[2]; acc.w += (float)out[3]; }
-    out[0] = (e)acc.x; out[1] = (e)acc.y; out[2] = (e)acc.z; out[3] = (e)acc.w;
+    if (p.accumulate) { const v4 o = *reinterpret_cast<const v4*>(out); acc.x += (float)o[0]; acc.y += (float)o[1]; acc.z += (float)o[2]; acc.w += (float)o[3]; }
+    v4 w; w[0] = (e)acc.x; w[1] = (e)acc.y; w[2] = (e)acc.z; w[3] = (e)acc.w;
+    *reinterpret_cast<v4*>(out) = w;
   }
 }
 
@@ -861,11 +877,11 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   if (dtype == DTA_BF16) {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 1>), gq, bq, 0, st, p); }
     if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_BF16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
-    if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_BF16>, dim3(n_splits * Hkv), dim3(256), 0, st, p);
+    if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_BF16>, dim3(n_splits * Hkv, FIN_SPLIT), dim3(256), 0, st, p);
   } else {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 1>), gq, bq, 0, st, p); }
     if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_F16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
-    if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_F16>, dim3(n_splits * Hkv), dim3(256), 0, st, p);
+    if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_F16>, dim3(n_splits * Hkv, FIN_SPLIT), dim3(256), 0, st, p);
   }
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
 }

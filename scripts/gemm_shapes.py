@@ -19,6 +19,9 @@ def timeit(fn, n=20):
 
 def main():
     T0 = int(sys.argv[1]) if len(sys.argv) > 1 else 25482
+    if len(sys.argv) > 2:                                   # "cublas" = rocBLAS, "cublaslt" = hipBLASLt (torch's default here)
+        torch.backends.cuda.preferred_blas_library(sys.argv[2])
+        print("preferred_blas_library:", torch.backends.cuda.preferred_blas_library())
     dev, dt = "cuda", torch.bfloat16
     shapes = [("qkv", 1024, 4096), ("o", 2048, 1024), ("gate_up", 1024, 6144), ("down", 3072, 1024), ("head", 1024, 151936)]
     Ts = sorted({T0, -(-T0 // 128) * 128, -(-T0 // 256) * 256, -(-T0 // 2048) * 2048})
