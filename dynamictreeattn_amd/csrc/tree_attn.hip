@@ -360,7 +360,8 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
   constexpr int NT = 256 * HPB, CPT = 1024 / NT;
   __shared__ __attribute__((aligned(16))) char smem[QK_LDS];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform values live in SGPRs
   const int hb = wave >> 2, rw = wave & 3;
   const int bid = blockIdx.x;
   const int hgroups = p.group / HPB;
@@ -399,9 +400,27 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
   const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
   const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.v_sh;
   u32x4 kreg[CPT], vreg[CPT]; int sereg = 0;
+  // chunk id = tid + NT*i -> image row id>>4, chunk id&15: the per-lane byte offset inside a 64-row tile is fixed for the
+  // sweep, so a tile's loads are <scalar tile base> + <32-bit lane offset> (no per-lane 64-bit address arithmetic)
+  uint32_t soff_k[CPT], soff_v[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int id = tid + NT * i, row = id >> 4, ch = id & 15;
+    soff_k[i] = (uint32_t)((row * p.kv_st + ch * 8) * (int64_t)sizeof(e));
+    soff_v[i] = (uint32_t)((row * p.v_st + ch * 8) * (int64_t)sizeof(e));
+  }
 #define DQ_LOAD(K0, KEND)                                                                                  \
-  { DTA_STAGE_LOAD(kreg, vreg, kbase, vbase, p.kv_st, p.v_st, (K0), p.Tk, NT, CPT)                        \
-    if (tid < 64) { const int ki_ = (K0) + tid; sereg = (ki_ < (KEND)) ? (p.subtree_end ? p.subtree_end[ki_] : 0x7fffffff) : 0; } }
+  { const int k0_ = (K0);                                                                                  \
+    if (k0_ + 64 <= p.Tk) {                                                                                \
+      const char* kb_ = reinterpret_cast<const char*>(kbase) + (int64_t)k0_ * p.kv_st * (int64_t)sizeof(e); \
+      const char* vb_ = reinterpret_cast<const char*>(vbase) + (int64_t)k0_ * p.v_st * (int64_t)sizeof(e);  \
+      _Pragma("unroll") for (int i_ = 0; i_ < CPT; ++i_) {                                                 \
+        uint32_t ok_ = soff_k[i_], ov_ = soff_v[i_];                                                       \
+        asm volatile("" : "+v"(ok_), "+v"(ov_));   /* keeps the 32->64-bit extension next to the load: scalar-base form */ \
+        kreg[i_] = *reinterpret_cast<const u32x4*>(kb_ + ok_);                                             \
+        vreg[i_] = *reinterpret_cast<const u32x4*>(vb_ + ov_); }                                           \
+    } else { DTA_STAGE_LOAD(kreg, vreg, kbase, vbase, p.kv_st, p.v_st, k0_, p.Tk, NT, CPT) }               \
+    if (tid < 64) { const int ki_ = k0_ + tid; sereg = (ki_ < (KEND)) ? (p.subtree_end ? p.subtree_end[ki_] : 0x7fffffff) : 0; } }
 #define DQ_WRITE(B)                                                                                        \
   { char* base_ = smem + (B) * (2 * TILE_BYTES + SE_BYTES);                                                \
     DTA_STAGE_WRITE(kreg, vreg, base_, base_ + TILE_BYTES, NT, CPT)                                        \
