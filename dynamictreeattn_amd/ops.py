@@ -533,8 +533,9 @@ def stack_rows(*ws: torch.Tensor) -> torch.Tensor:
 
 class _Linear(torch.autograd.Function):
     """y = x Wᵀ (+ b) over packed rows with the weight-gradient GEMM issued in the layout hipBLASLt runs faster on
-    gfx950: for a projection that narrows (in > out: o_proj, down_proj) `xᵀ·dy` (then viewed transposed) is 1.2-1.5×
-    faster than autograd's `dyᵀ·x`; for the widening ones it is the other way round (scripts/gemm_wgrad_variants.py)."""
+    gfx950: for a projection that narrows by 2x or more (Qwen3-0.6B o_proj 2048->1024, down_proj 3072->1024) `xᵀ·dy`
+    (then viewed transposed) is 1.2-1.5× faster than autograd's `dyᵀ·x`; for the widening ones and for mild narrowing
+    (Qwen3-4B o_proj 4096->2560) it is the other way round (scripts/gemm_wgrad_variants.py, both geometries)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -548,7 +549,7 @@ class _Linear(torch.autograd.Function):
         dx = dy @ w if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = dy.t() @ x if w.shape[0] >= w.shape[1] else (x.t() @ dy).t()
+            dw = (x.t() @ dy).t() if w.shape[1] >= 2 * w.shape[0] else dy.t() @ x
         db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 

@@ -11,7 +11,9 @@ def timeit(fn, n=20):
     return a.elapsed_time(b) / n
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 25482
 dev, dt = "cuda", torch.bfloat16
-for name, K, N in [("qkv", 1024, 4096), ("o", 2048, 1024), ("gate_up", 1024, 6144), ("down", 3072, 1024)]:
+SHAPES = {"0.6b": [("qkv", 1024, 4096), ("o", 2048, 1024), ("gate_up", 1024, 6144), ("down", 3072, 1024)],
+          "4b": [("qkv", 2560, 6144), ("o", 4096, 2560), ("gate_up", 2560, 19456), ("down", 9728, 2560)]}
+for name, K, N in SHAPES[sys.argv[2] if len(sys.argv) > 2 else "0.6b"]:
     for TT in (T, -(-T // 256) * 256):
         x = torch.randn(TT, K, device=dev, dtype=dt); dy = torch.randn(TT, N, device=dev, dtype=dt)
         fl = 2.0 * TT * K * N / 1e9
