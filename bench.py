@@ -151,12 +151,22 @@ def main():
     # same here — bins are planned before the clock starts, everything from TokenTrie(...) on is timed.
     my_seqs = [[seqs[i] for i in dp.my_bin(seqs, rank, world, "backward", args.block_size)] for seqs in batches]
 
+    # N > 1: plain post-backward gradient all-reduce (SUM, no averaging) by default; DTA_BENCH_OVERLAP=1 runs it bucket by
+    # bucket under the backward pass (dp.OverlappedGradAllReduce, gloo-tested; opt-in until it has run on RCCL: this
+    # round's GPU boxes have one GPU)
+    overlap = world > 1 and os.environ.get("DTA_BENCH_OVERLAP", "0") == "1"
+    reducer = dp.OverlappedGradAllReduce(model.parameters()) if overlap else None
+
     def step(mine, timed: bool):
         model.zero_grad(set_to_none=True)
         trie = TokenTrie(mine, [dict(ATTACH) for _ in mine])
         trie.backward_permute()
+        if reducer is not None:
+            reducer.start()
         loss = engine.backward(model, trie, loss_fn, args.block_size)
-        if world > 1:
+        if reducer is not None:
+            reducer.finish()
+        elif world > 1:
             dp.allreduce_grads(model.parameters())
         if timed:
             st = trie.get_stats("backward", args.block_size)
@@ -223,7 +233,7 @@ def main():
         "config": {"workload": "tau2-16k-shaped trie batch (8 rollouts x 6 turns, 2000-token shared prompt, 48 seqs ~180k tokens "
                                f"per call), one call per GPU per step, {MODEL_NAME[args.model]} random-init bf16, tree fwd+bwd, block_size {args.block_size}, permute=ours",
                    "calls_per_step": world, "balancer": "LB_by_DFS_and_TM" if world > 1 else "none",
-                   "grad_allreduce": "RCCL sum" if world > 1 else "none"},
+                   "grad_allreduce": ("RCCL sum, 256 MB buckets overlapped with backward" if overlap else "RCCL sum after backward") if world > 1 else "none"},
         "tree_tokens_per_s": n_tree / wall,
         "roofline": {"bound": "mfma", "kernel": "tree_attn_bwd_dkv_kernel", "achieved": dkv_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": dkv_tf / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dkv_ms,

@@ -44,3 +44,72 @@ def allreduce_grads(params, group=None, bucket_bytes: int = 1 << 29) -> None:
         o = 0
         for g in chunk:
             g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
+
+
+class OverlappedGradAllReduce:
+    """The same ONE logical all-reduce(SUM) as `allreduce_grads`, overlapped with the backward pass (SURVEY §8e:
+    "bucketed and overlapped").  Parameters are cut into flat buckets in the order their gradients become ready
+    (reverse registration order: last layer first, the embedding last); a post-accumulate-grad hook counts a bucket
+    down and, once it is complete, enqueues its asynchronous all-reduce — strictly in bucket order, so every rank
+    issues the collectives in the same sequence whatever the readiness order inside a layer.  `finish()` launches
+    whatever did not complete (parameters without a gradient this step), waits, and copies the sums back.
+
+        red = OverlappedGradAllReduce(model.parameters())
+        red.start(); engine.backward(...); red.finish()
+    """
+
+    def __init__(self, params, group=None, bucket_bytes: int = 1 << 28):
+        self.group = group
+        ps = [p for p in params if p.requires_grad]
+        self.buckets: List[List[torch.nn.Parameter]] = []
+        cur, n = [], 0
+        for p in reversed(ps):
+            b = p.numel() * p.element_size()
+            if cur and (n + b > bucket_bytes or p.dtype != cur[0].dtype):
+                self.buckets.append(cur); cur, n = [], 0
+            cur.append(p); n += b
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in ps]
+        self._active = False
+
+    def start(self) -> None:
+        self._left = [len(b) for b in self.buckets]
+        self._next = 0                    # next bucket index to launch
+        self._works = []
+        self._active = True
+
+    def _on_grad(self, p) -> None:
+        if not self._active:
+            return
+        self._left[self._bucket_of[id(p)]] -= 1
+        while self._next < len(self.buckets) and self._left[self._next] <= 0:
+            self._launch(self._next); self._next += 1
+
+    def _launch(self, i: int) -> None:
+        grads = [p.grad for p in self.buckets[i] if p.grad is not None]
+        if not grads:
+            self._works.append(None); return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append((work, flat, grads))
+
+    def finish(self) -> None:
+        self._active = False
+        while self._next < len(self.buckets):
+            self._launch(self._next); self._next += 1
+        for w in self._works:
+            if w is None:
+                continue
+            work, flat, grads = w
+            work.wait()
+            o = 0
+            for g in grads:
+                g.copy_(flat[o:o + g.numel()].view_as(g)); o += g.numel()
+        self._works = []
+
+    def close(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -24,7 +24,7 @@ def _init(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
-def _dp_worker(rank, world, port, name, q):
+def _dp_worker(rank, world, port, name, q, overlapped=False):
     import sys
     sys.path.insert(0, os.path.dirname(__file__)); sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
     import hostmirror
@@ -46,21 +46,31 @@ def _dp_worker(rank, world, port, name, q):
     att = [{"w_logprobs": -1.0 - 0.01 * i, "w_entropy": 0.1 + 0.003 * i} for i in range(len(seqs))]
     ids = dp.my_bin(seqs, rank, world, "backward", 2048)
     t = token_trie.TokenTrie([seqs[i] for i in ids], [att[i] for i in ids]); t.backward_permute()
-    loss = tree_training_engine.TreeTrainingEngine(model.config, "cpu", torch.float32, 4096).backward(model, t, mo.default_loss, 2048)
-    dp.allreduce_grads(model.parameters())
+    eng = tree_training_engine.TreeTrainingEngine(model.config, "cpu", torch.float32, 4096)
+    if overlapped:
+        # tiny buckets: several collectives are in flight while the backward is still running; a second step re-uses the hooks
+        red = dp.OverlappedGradAllReduce(model.parameters(), bucket_bytes=20000)
+        assert len(red.buckets) > 2
+        for _ in range(2):
+            model.zero_grad(set_to_none=True)
+            red.start(); loss = eng.backward(model, t, mo.default_loss, 2048); red.finish()
+        red.close()
+    else:
+        loss = eng.backward(model, t, mo.default_loss, 2048)
+        dp.allreduce_grads(model.parameters())
     lt = torch.tensor([loss], dtype=torch.float64); dist.all_reduce(lt)
     torch.save({"loss": float(lt), "ids": sorted(ids), "grads": {n: p.grad.clone() for n, p in model.named_parameters()} if rank == 0 else None},
                os.path.join(q, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["d128_minitau", "d128_tree"])
-def test_trie_sharded_dp_grads_equal_full_batch(name):
+@pytest.mark.parametrize("name,overlapped", [("d128_minitau", False), ("d128_tree", False), ("d128_minitau", True), ("d128_tree", True)])
+def test_trie_sharded_dp_grads_equal_full_batch(name, overlapped):
     from oracle import model_oracle as mo
     gold = torch.load(os.path.join(GOLD, "engine_tiny.pt"), weights_only=True)[name]
     import tempfile
     ctx = mp.get_context("spawn"); q = tempfile.mkdtemp(); port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, name, q, overlapped)) for r in range(2)]
     [p.start() for p in procs]
     [p.join(300) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
