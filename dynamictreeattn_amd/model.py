@@ -142,17 +142,60 @@ def _layer_forward(layer, res, delta, cos_sin, meta, Hq, Hkv, D, eps):
     return res, ops.linear(act, m.down_proj.weight)
 
 
-def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta, checkpoint_layers: bool = False) -> torch.Tensor:
+class _LayerRecompute(torch.autograd.Function):
+    """Per-layer activation recomputation (for tries whose activations do not fit): the forward runs the layer
+    without a graph and keeps only its two inputs — plus, when `keep_attn`, the attention output and lse, so that the
+    recomputation in the backward skips the forward attention kernel (a fifth of the attention time at depth).  The
+    backward re-runs the layer with a graph and back-propagates through it; parameter gradients accumulate into
+    `.grad` directly (nested autograd), input gradients are returned."""
+
+    @staticmethod
+    def forward(ctx, fn, keep_attn, res, delta):
+        ctx.fn, ctx.has_delta = fn, delta is not None
+        items = []
+        with torch.no_grad():
+            if keep_attn:
+                with ops.AttentionTape("record", items):
+                    out = fn(res, delta)
+            else:
+                out = fn(res, delta)
+        ctx.items = items
+        ctx.save_for_backward(res, delta if delta is not None else res)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_res, g_delta):
+        res, delta = ctx.saved_tensors
+        r = res.detach().requires_grad_(True)
+        d = delta.detach().requires_grad_(True) if ctx.has_delta else None
+        with torch.enable_grad():
+            if ctx.items:
+                with ops.AttentionTape("replay", ctx.items):
+                    o_res, o_delta = ctx.fn(r, d)
+            else:
+                o_res, o_delta = ctx.fn(r, d)
+        ctx.items = None
+        torch.autograd.backward((o_res, o_delta), (g_res, g_delta))
+        return None, None, r.grad, (d.grad if d is not None else None)
+
+
+def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta, checkpoint_layers: bool = False,
+                         attn_keep_bytes: int = 0) -> torch.Tensor:
     """Final-norm hidden states [T, hidden] of the packed tokens.  `model` is a Qwen3TreeLM or an HF
-    Qwen2/Qwen3 *ForCausalLM (duck-typed)."""
+    Qwen2/Qwen3 *ForCausalLM (duck-typed).  `checkpoint_layers`: recompute each layer in the backward;
+    `attn_keep_bytes`: HBM budget for attention outputs kept across that recomputation (layers are served first to last)."""
     Hq, Hkv, D, eps, theta = _cfg_of(model)
     body = model.model
     res, delta = F.embedding(tokens, body.embed_tokens.weight), None
     cos_sin = ops.rope_cos_sin(depth, D, theta)
+    per_layer = tokens.shape[0] * Hq * (D * res.element_size() + 4)             # out + lse of one layer
     for layer in body.layers:
         if checkpoint_layers and torch.is_grad_enabled():
-            from torch.utils.checkpoint import checkpoint
-            res, delta = checkpoint(_layer_forward, layer, res, delta, cos_sin, meta, Hq, Hkv, D, eps, use_reentrant=False)
+            keep = attn_keep_bytes >= per_layer
+            if keep:
+                attn_keep_bytes -= per_layer
+            fn = (lambda layer_: lambda r_, d_: _layer_forward(layer_, r_, d_, cos_sin, meta, Hq, Hkv, D, eps))(layer)
+            res, delta = _LayerRecompute.apply(fn, keep, res, delta)
         else:
             res, delta = _layer_forward(layer, res, delta, cos_sin, meta, Hq, Hkv, D, eps)
     return ops.add_rms_norm(res, delta, body.norm.weight, eps)[1]

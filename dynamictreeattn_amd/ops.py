@@ -121,10 +121,38 @@ def attn_bwd_raw(q, k, v, out, dout, lse, meta: TreeAttnMeta, scale: float, dk=N
     return dq, dk, dv
 
 
+class AttentionTape:
+    """Keeps the attention outputs (out, lse) of a no-grad forward so that a later recomputation of the same layer
+    (per-layer activation recomputation in the engine) does not run the forward attention kernel again: in
+    "record" mode `tree_attention` appends what it produced, in "replay" mode it takes the next entry instead of
+    launching the kernel.  q, k, v come from the recomputed projections either way (the backward needs them)."""
+    current = None
+
+    def __init__(self, mode: str, items=None):
+        assert mode in ("record", "replay")
+        self.mode, self.items, self.pos = mode, ([] if items is None else items), 0
+
+    def __enter__(self):
+        self._prev, AttentionTape.current = AttentionTape.current, self
+        return self
+
+    def __exit__(self, *exc):
+        AttentionTape.current = self._prev
+        return False
+
+
 class _TreeAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, meta: TreeAttnMeta, scale: float):
-        out, lse, k, v = attn_fwd_raw(q, k, v, meta, scale)
+        tape = AttentionTape.current
+        if tape is not None and tape.mode == "replay" and tape.pos < len(tape.items):
+            out, lse = tape.items[tape.pos]; tape.pos += 1
+            if out.shape != q.shape:
+                raise RuntimeError("attention replay: recorded output does not match the recomputed query")
+        else:
+            out, lse, k, v = attn_fwd_raw(q, k, v, meta, scale)
+            if tape is not None and tape.mode == "record":
+                tape.items.append((out, lse))
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.meta, ctx.scale = meta, scale
         return out

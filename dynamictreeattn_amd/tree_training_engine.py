@@ -162,6 +162,7 @@ class TreeTrainingEngine:
         self.last_packed: Optional[_PackedTrie] = None
         self.head_chunk = 2048
         self.checkpoint_layers: Optional[bool] = None    # None = decide from free HBM
+        self.attn_keep_fraction = 0.25                   # of free HBM, for attention outputs kept across layer recomputation
         self.tp_group = None                             # set to a process group to split the LM-head vocabulary across it
 
     # ------------------------------------------------------------------------------------------
@@ -184,6 +185,15 @@ class TreeTrainingEngine:
             return False
         free, _ = torch.cuda.mem_get_info(self.device)
         return need > 0.6 * free
+
+    def _attn_keep_bytes(self) -> int:
+        """HBM budget for attention outputs kept across the per-layer recomputation (model.py:_LayerRecompute): a quarter
+        of what is free when the pass starts, so the recomputation skips the forward attention kernel on as many layers
+        as that pays for.  `attn_keep_fraction = 0` recomputes everything."""
+        if self.device.type != "cuda" or self.attn_keep_fraction <= 0:
+            return 0
+        free, _ = torch.cuda.mem_get_info(self.device)
+        return int(self.attn_keep_fraction * free)
 
     def _path_losses(self, packed, token_trie, lp, ent, loss_fn):
         total = None
@@ -222,7 +232,8 @@ class TreeTrainingEngine:
         self.forkpos_list = _get_forkpos(lens, token_trie.lcp_lens, block_size)
         packed = self._pack(token_trie)
         chunk = min(self.head_chunk, block_size) if block_size else self.head_chunk
-        h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, self._should_checkpoint(model, packed.plan.T))
+        ckpt = self._should_checkpoint(model, packed.plan.T)
+        h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, ckpt, self._attn_keep_bytes() if ckpt else 0)
         lp, ent = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, True, max(chunk, 1),
                                          packed.fork_child, packed.fork_parent, self.tp_group)
         total = self._path_losses(packed, token_trie, lp, ent, loss_fn)

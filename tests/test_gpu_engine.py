@@ -92,6 +92,23 @@ def test_f16_and_layer_checkpointing_agree():
     l2 = e.backward(m, t, mo.default_loss, 64)
     assert abs(l1 - l2) < 1e-3 * abs(l1)
     assert max(mo.grad_ratio(g1[n], p.grad.float()) for n, p in m.named_parameters()) < 5e-3
+    # the recomputation keeps attention outputs when HBM allows: one forward attention launch per layer instead of two,
+    # and bit-identical gradients either way (the replayed output IS the recorded one)
+    from dynamictreeattn_amd import ops
+    counts, grads = [], []
+    for frac in (0.25, 0.0):
+        m.zero_grad(set_to_none=True)
+        e.attn_keep_fraction = frac
+        tm = ops.KernelTimer(); ops.KernelTimer.active = tm
+        try:
+            e.backward(m, t, mo.default_loss, 64)
+        finally:
+            ops.KernelTimer.active = None
+        counts.append(tm.totals_ms()["fwd"][1])
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters()})
+    L = m.config.num_hidden_layers
+    assert counts == [L, 2 * L]
+    assert all(torch.equal(grads[0][n], grads[1][n]) for n in grads[0])
 
 
 def test_qwen3_0p6b_config1_tree_vs_dense_within_recorded_bound():

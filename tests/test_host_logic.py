@@ -185,6 +185,21 @@ def test_engine_padding_changes_nothing(monkeypatch):
         assert mo.grad_ratio(outs[1][1][k], outs[0][1][k]) < 1e-5, k
 
 
+def test_layer_recomputation_gives_the_same_gradients():
+    m, seqs = _model("d128_tree")
+    outs = []
+    for ck in (False, True):
+        m.zero_grad(set_to_none=True)
+        t = TokenTrie(seqs, _att(len(seqs)), device=CPU); t.backward_permute()
+        eng = TreeTrainingEngine(m.config, CPU, torch.float32, 4096)
+        eng.checkpoint_layers = ck
+        loss = eng.backward(m, t, mo.default_loss, 2048)
+        outs.append((float(loss), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[0][0])
+    for k in outs[0][1]:
+        assert mo.grad_ratio(outs[1][1][k], outs[0][1][k]) < 1e-6, k
+
+
 @pytest.fixture(scope="module")
 def eng_gold():
     return torch.load(os.path.join(GOLD, "engine_tiny.pt"), weights_only=True)
