@@ -12,6 +12,8 @@ torch.  `Qwen3TreeLM` mirrors the HF module/parameter tree (``model.embed_tokens
 """
 from __future__ import annotations
 
+import os
+
 from types import SimpleNamespace
 
 import torch
@@ -20,7 +22,7 @@ import torch.nn.functional as F
 
 from . import ops
 
-FUSE_PROJECTIONS = __import__("os").environ.get("DTA_FUSE_PROJ", "1") != "0"      # diagnostic A/B switch
+FUSE_PROJECTIONS = os.environ.get("DTA_FUSE_PROJ", "1") != "0"      # diagnostic A/B switch
 
 
 class _Norm(nn.Module):

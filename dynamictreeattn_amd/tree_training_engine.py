@@ -23,6 +23,8 @@ left to cut (no token is forwarded twice) and is accepted for signature parity.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, List, Optional
 
 import numpy as np
@@ -92,7 +94,8 @@ def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tenso
 class _PackedTrie:
     """Device-resident packed form of a TokenTrie (in its current leaf order)."""
 
-    PAD_FROM = int(__import__("os").environ.get("DTA_PAD_FROM", 2048))   # packed lengths from here on are rounded up to PAD_TO rows of filler (packing.pad_plan); env = diagnostic A/B switch
+    # packed lengths from PAD_FROM on are rounded up to PAD_TO rows of filler (packing.pad_plan); the env var is a diagnostic A/B switch
+    PAD_FROM = int(os.environ.get("DTA_PAD_FROM", 2048))
     PAD_TO = 256
 
     def __init__(self, trie, device, n_kv_heads: int = 8):
