@@ -32,6 +32,7 @@ from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine
 MODEL_NAME = {"qwen3-0.6b": "Qwen3-0.6B", "qwen3-4b": "Qwen3-4B"}
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16 peak, MI355X_MICROARCH.md "Chip-level parameters"
 ATTACH = {"w_logprobs": -1.0, "w_entropy": 0.1}      # run_all.py:11-14
+DKV_KERNEL = "tree_attn_bwd_dkv2_kernel"             # the dominant kernel as rocprofv3 names it (8-wave dK/dV)
 
 
 def loss_fn(logprob, entropy, attachment):            # run.py:149-152
@@ -221,7 +222,7 @@ def main():
         cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_attn_traffic.json")))
         if cand:
             tj = json.load(open(cand[-1]))
-            traffic = tj["kernels"]["tree_attn_bwd_dkv_kernel"]["hbm_bytes_per_launch"]
+            traffic = tj["kernels"][DKV_KERNEL]["hbm_bytes_per_launch"]
             traffic_src = os.path.relpath(cand[-1], ROOT) + " (tau2 seed-0 trie, one layer; 2*FETCH_SIZE+WRITE_SIZE)"
     except Exception:
         pass
@@ -235,7 +236,7 @@ def main():
                    "calls_per_step": world, "balancer": "LB_by_DFS_and_TM" if world > 1 else "none",
                    "grad_allreduce": ("RCCL sum, 256 MB buckets overlapped with backward" if overlap else "RCCL sum after backward") if world > 1 else "none"},
         "tree_tokens_per_s": n_tree / wall,
-        "roofline": {"bound": "mfma", "kernel": "tree_attn_bwd_dkv_kernel", "achieved": dkv_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+        "roofline": {"bound": "mfma", "kernel": DKV_KERNEL, "achieved": dkv_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": dkv_tf / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dkv_ms,
                      "flops_per_pair_per_layer": 8 * Hq * D, "pairs_per_step": pairs / max(args.steps, 1),
                      "other_kernels": {"tree_attn_fwd_kernel": {"achieved": fwd_tf, "avg_launch_ms": fwd_ms, "flops_per_pair_per_layer": 4 * Hq * D},

@@ -152,7 +152,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 #define DTA_ABL_E(real, fake) ((DTA_ABL & 1) ? (fake) : (real))
 #define DTA_ABL_A(real, fake) ((DTA_ABL & 2) ? (fake) : (real))
 #define DTA_ABL_B(real, fake) ((DTA_ABL & 4) ? (fake) : (real))
-// 8 = no per-tile barrier in the forward (races: timing only); 16 = forward with one head per workgroup (valid results)
+// 8 = no per-tile barrier in the forward (races: timing only); 16 = forward with one head per workgroup (valid results); 128 = the 4-wave dK/dV kernel instead of the 8-wave one (valid results)
 
 // Per-lane byte offsets of every fragment read inside one image, computed once: the XOR swizzle depends on the
 // lane only (row blocks of 32 and k-steps of 16 rows leave row&3 and (row>>2)&3 unchanged), so inside the tile
@@ -781,6 +781,233 @@ __global__ __launch_bounds__(256 * NG) void tree_attn_bwd_dkv_kernel(AttnParams 
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// dK/dV with TWO waves per SIMD (8 waves): the two wave groups own the same 128 keys and split every 64-row query tile
+// between them (group g takes rows 32g..32g+31), so they share ONE double-buffered Q/dO image.  To fit 256 registers
+// the K/V fragments (pure MFMA B operands) live in LDS in fragment order (one lane-linear, conflict-free ds_read_b128
+// per use) instead of 64 registers.  The groups' partial dK/dV are summed through LDS in a fixed order at the end.
+// -------------------------------------------------------------------------------------------------
+constexpr int KV2_FRAGS = 4 * 16384;                                // 4 key slots x {K: 8 fragments x 1 KiB, V: 8 x 1 KiB}
+constexpr int KV2_BUF = 2 * TILE_BYTES + 512;
+constexpr int KV2_LDS = KV2_FRAGS + 2 * KV2_BUF;
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p) {
+  using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
+  constexpr int KT = 128;
+  __shared__ __attribute__((aligned(16))) char smem_all[KV2_LDS];
+  const int tid8 = threadIdx.x, tid = tid8 & 255, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid8 >> 6);       // 0..7
+  const int grp = wave8 >> 2, wave = wave8 & 3;
+  char* kvs = smem_all + wave * 16384;                               // this key slot's K fragments (+8192: V)
+  char* smem = smem_all + KV2_FRAGS;                                 // the Q/dO buffers
+  const int bid = blockIdx.x;
+  const int kvh = bid % p.Hkv; const int unit = bid / p.Hkv;
+  const int kt = p.dkv_units ? p.dkv_units[4 * unit] : unit;
+  const int slab = p.dkv_units ? p.dkv_units[4 * unit + 3] : -1;
+  const int k0 = kt * KT;
+  const int q_hi = p.q_offset + p.Tq;
+  const int kidx = k0 + wave * 32 + r;
+  int se_l;
+  { const int kc = kidx < p.Tk ? kidx : p.Tk - 1;
+    int se = (kidx < p.Tk) ? (p.subtree_end ? p.subtree_end[kidx] : 0x7fffffff) : 0;
+    se_l = se < q_hi ? se : q_hi;
+    if (grp == 0) {                                                  // group 0 stages the fragments both groups read
+      const e* kp = reinterpret_cast<const e*>(p.k) + (int64_t)kc * p.kv_st + (int64_t)kvh * p.kv_sh;
+      const e* vp = reinterpret_cast<const e*>(p.v) + (int64_t)kc * p.v_st + (int64_t)kvh * p.v_sh;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        *reinterpret_cast<v8*>(kvs + s * 1024 + lane * 16) = *reinterpret_cast<const v8*>(kp + 16 * s + 8 * h);
+        *reinterpret_cast<v8*>(kvs + 8192 + s * 1024 + lane * 16) = *reinterpret_cast<const v8*>(vp + 16 * s + 8 * h);
+      }
+    } }
+  __shared__ int se_min_s[4];
+  { int mn = se_l;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
+    if (lane == 0 && grp == 0) se_min_s[wave] = mn; }
+  __syncthreads();
+  const int se_min = __builtin_amdgcn_readfirstlane(min(min(se_min_s[0], se_min_s[1]), min(se_min_s[2], se_min_s[3])));
+
+  const FragOffs offs = frag_offsets(lane);
+  f32x16 DK[4], DV[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { DK[db][g] = 0.f; DV[db][g] = 0.f; }
+
+  int qbeg, qend;
+  if (p.dkv_units) { qbeg = __builtin_amdgcn_readfirstlane(p.dkv_units[4 * unit + 1]); qend = __builtin_amdgcn_readfirstlane(p.dkv_units[4 * unit + 2]); }
+  else {
+    qbeg = k0 > p.q_offset ? k0 : p.q_offset;
+    qend = p.ktile_qend ? p.ktile_qend[kt] : q_hi; qend = qend < q_hi ? qend : q_hi;
+  }
+  const int ntile = qend > qbeg ? (qend - qbeg + 63) / 64 : 0;
+  const int total = ntile * p.group;
+  const float c = p.scale * LOG2E;
+
+  // tile DMA: 16 one-KiB pieces per image over 8 waves = 2 per wave per image (piece = 2*wave8 + i: rows 8*wave8 + 4*i ..)
+  uint32_t voff_q[2], voff_d[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row_ = 8 * wave8 + 4 * i + (lane >> 4);
+    const int ch_ = (lane & 15) ^ (((row_ & 3) << 2) | ((row_ >> 2) & 3));
+    voff_q[i] = (uint32_t)((row_ * p.q_st + ch_ * 8) * (int64_t)sizeof(e));
+    voff_d[i] = (uint32_t)((row_ * p.o_st + ch_ * 8) * (int64_t)sizeof(e));
+  }
+#define KV2_DMA(HG, TI, B)                                                                                 \
+  { const int hq_ = __builtin_amdgcn_readfirstlane(kvh * p.group + (HG));                                   \
+    const int row0_ = qbeg + 64 * (TI) - p.q_offset;                                                       \
+    char* base_ = smem + (B) * KV2_BUF;                                                                    \
+    if (wave8 < 2) { int qr_ = row0_ + lane; qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;   /* wave 0: lse[64], wave 1: delta[64] */ \
+      const float* src_ = (wave8 == 0 ? p.lse_r : p.delta) + (int64_t)hq_ * p.Tq;                          \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + qr_),        \
+                                       (__attribute__((address_space(3))) void*)(base_ + 2 * TILE_BYTES + wave8 * 256), 4, 0, 0); } \
+    const char* qb_ = reinterpret_cast<const char*>(p.q) + ((int64_t)hq_ * p.q_sh + (int64_t)row0_ * p.q_st) * (int64_t)sizeof(e);    \
+    const char* db_ = reinterpret_cast<const char*>(p.dout) + ((int64_t)hq_ * p.o_sh + (int64_t)row0_ * p.o_st) * (int64_t)sizeof(e); \
+    if (row0_ + 64 <= p.Tq) {                                                                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                   \
+        uint32_t oq_ = voff_q[i_], od_ = voff_d[i_];                                                       \
+        asm volatile("" : "+v"(oq_), "+v"(od_));                                                           \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb_ + oq_),       \
+                                         (__attribute__((address_space(3))) void*)(base_ + (wave8 * 2 + i_) * 1024), 16, 0, 0);              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + od_),       \
+                                         (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + (wave8 * 2 + i_) * 1024), 16, 0, 0); } \
+    } else {                                       /* ragged last tile of the tensor: clamp the row per lane */ \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                   \
+        const int row_ = 8 * wave8 + 4 * i_ + (lane >> 4);                                                 \
+        const int ch_ = (lane & 15) ^ (((row_ & 3) << 2) | ((row_ >> 2) & 3));                              \
+        const int rr_ = row0_ + row_ < p.Tq ? row_ : p.Tq - 1 - row0_;                                     \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb_ + ((int64_t)rr_ * p.q_st + ch_ * 8) * (int64_t)sizeof(e)), \
+                                         (__attribute__((address_space(3))) void*)(base_ + (wave8 * 2 + i_) * 1024), 16, 0, 0);              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + ((int64_t)rr_ * p.o_st + ch_ * 8) * (int64_t)sizeof(e)), \
+                                         (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + (wave8 * 2 + i_) * 1024), 16, 0, 0); } } }
+
+  {
+    int hg_c = 0, ti_c = 0;
+    if (total > 0) KV2_DMA(hg_c, ti_c, 0)
+    __syncthreads();
+    int cur = 0;
+    for (int idx = 0; idx < total; ++idx) {
+      const int ti = ti_c;
+      ti_c += 1;
+      if (ti_c >= ntile) { ti_c = 0; ++hg_c; }
+      if (idx + 1 < total) KV2_DMA(hg_c, ti_c, cur ^ 1)
+      const float* lse_s = reinterpret_cast<const float*>(smem + cur * KV2_BUF + 2 * TILE_BYTES); const float* del_s = lse_s + 64;
+      const int qi0 = qbeg + 64 * ti + 32 * grp;                       // packed index of this group's first row
+      const bool full = (qbeg + 64 * ti >= k0 + KT - 1) && (qbeg + 64 * ti + 63 < se_min);   // workgroup-uniform: no mask needed
+      const int sb = cur * KV2_BUF + grp * (32 * 256);
+      int ar[8], at[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ar[j] = offs.row[j] + sb; at[j] = offs.tr[j] + sb; }
+      f32x16 S, DP;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) { S[g] = 0.f; DP[g] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const v8 aq = *reinterpret_cast<const v8*>(smem + ar[s]);
+        const v8 ad = *reinterpret_cast<const v8*>(smem + ar[s] + TILE_BYTES);
+        const v8 kfs = *reinterpret_cast<const v8*>(kvs + s * 1024 + lane * 16);
+        const v8 vfs = *reinterpret_cast<const v8*>(kvs + 8192 + s * 1024 + lane * 16);
+        S = T::mma(aq, kfs, S); DP = T::mma(ad, vfs, DP);
+      }
+      float nl[16], dl[16];
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int ql = 32 * grp + 8 * gq + 4 * h;
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + ql);
+        const float4 d4 = *reinterpret_cast<const float4*>(del_s + ql);
+        nl[4 * gq] = l4.x; nl[4 * gq + 1] = l4.y; nl[4 * gq + 2] = l4.z; nl[4 * gq + 3] = l4.w;
+        dl[4 * gq] = d4.x; dl[4 * gq + 1] = d4.y; dl[4 * gq + 2] = d4.z; dl[4 * gq + 3] = d4.w;
+      }
+      if (full) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const float pv = fast_exp2(__builtin_fmaf(S[g], c, -nl[g]));
+          S[g] = pv;
+          DP[g] = pv * (DP[g] - dl[g]);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int qi = qi0 + 8 * (g >> 2) + 4 * h + (g & 3);
+          const bool ok = (kidx <= qi) && (qi < se_l);
+          const float pv = ok ? fast_exp2(__builtin_fmaf(S[g], c, -nl[g])) : 0.f;
+          S[g] = pv;
+          DP[g] = pv * (DP[g] - dl[g]);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const v8 pb = pack_half<DT>(S, s2), sbf = pack_half<DT>(DP, s2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const v8 adt = tr_pair<v8>(smem + at[db] + TILE_BYTES + 4096 * s2, smem + at[4 + db] + TILE_BYTES + 4096 * s2);
+          const v8 aqt = tr_pair<v8>(smem + at[db] + 4096 * s2, smem + at[4 + db] + 4096 * s2);
+          DV[db] = T::mma(adt, pb, DV[db]); DK[db] = T::mma(aqt, sbf, DK[db]);
+        }
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+#undef KV2_DMA
+  {
+    // group 1 hands its partial sums to group 0 through LDS, 32 accumulators (one d-block of dK and dV) at a time
+    float* red = reinterpret_cast<float*>(smem_all);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      if (grp == 1) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { red[g * 256 + tid] = DK[db][g]; red[(16 + g) * 256 + tid] = DV[db][g]; }
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { DK[db][g] += red[g * 256 + tid]; DV[db][g] += red[(16 + g) * 256 + tid]; }
+      }
+      __syncthreads();
+    }
+    if (grp == 1) return;
+  }
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) DK[db][g] *= p.scale;
+  const int kloc = wave * 32 + r;
+  if (slab >= 0) {
+    float* ws = p.dkv_ws + ((int64_t)slab * p.Hkv + kvh) * (2 * KT * 128) + (int64_t)kloc * 128;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = 32 * db + 8 * gq + 4 * h;
+        *reinterpret_cast<float4*>(ws + d) = make_float4(DK[db][4 * gq], DK[db][4 * gq + 1], DK[db][4 * gq + 2], DK[db][4 * gq + 3]);
+        *reinterpret_cast<float4*>(ws + KT * 128 + d) = make_float4(DV[db][4 * gq], DV[db][4 * gq + 1], DV[db][4 * gq + 2], DV[db][4 * gq + 3]);
+      }
+  } else if (kidx < p.Tk) {
+    e* dkp = reinterpret_cast<e*>(p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+    e* dvp = reinterpret_cast<e*>(p.dv) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = 32 * db + 8 * gq + 4 * h;
+        v4 wk, wv;
+        if (p.accumulate) {
+          const v4 ok_ = *reinterpret_cast<const v4*>(dkp + d); const v4 ov_ = *reinterpret_cast<const v4*>(dvp + d);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { wk[j] = (e)(DK[db][4 * gq + j] + (float)ok_[j]); wv[j] = (e)(DV[db][4 * gq + j] + (float)ov_[j]); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { wk[j] = (e)DK[db][4 * gq + j]; wv[j] = (e)DV[db][4 * gq + j]; }
+        }
+        *reinterpret_cast<v4*>(dkp + d) = wk;
+        *reinterpret_cast<v4*>(dvp + d) = wv;
+      }
+  }
+}
+
 // Sums the fp32 slabs of every split key tile in a fixed order and writes dK/dV (bitwise reproducible).
 // dkv_splits[s] = {key tile, first slab, number of slabs, 0}.
 constexpr int FIN_SPLIT = 8;          // blockIdx.y: each (split key tile, kv head) is summed by 8 workgroups — the sums are load-latency bound
@@ -895,11 +1122,13 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   const dim3 gq(pair ? nqt * Hq / 2 : nqt * Hq), bq(pair ? 512 : 256);
   if (dtype == DTA_BF16) {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 1>), gq, bq, 0, st, p); }
-    if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_BF16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
+    if (which & 2) { if (!(DTA_ABL & 128)) hipLaunchKernelGGL((tree_attn_bwd_dkv2_kernel<DTA_BF16>), dim3(ndkv * Hkv), dim3(512), 0, st, p);
+                     else hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_BF16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p); }
     if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_BF16>, dim3(n_splits * Hkv, FIN_SPLIT), dim3(256), 0, st, p);
   } else {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 1>), gq, bq, 0, st, p); }
-    if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_F16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
+    if (which & 2) { if (!(DTA_ABL & 128)) hipLaunchKernelGGL((tree_attn_bwd_dkv2_kernel<DTA_F16>), dim3(ndkv * Hkv), dim3(512), 0, st, p);
+                     else hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_F16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p); }
     if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_F16>, dim3(n_splits * Hkv, FIN_SPLIT), dim3(256), 0, st, p);
   }
   return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
