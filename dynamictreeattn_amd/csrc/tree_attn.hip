@@ -152,7 +152,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 #define DTA_ABL_E(real, fake) ((DTA_ABL & 1) ? (fake) : (real))
 #define DTA_ABL_A(real, fake) ((DTA_ABL & 2) ? (fake) : (real))
 #define DTA_ABL_B(real, fake) ((DTA_ABL & 4) ? (fake) : (real))
-// 8 = no per-tile barrier in the forward (races: timing only); 16 = forward with one head per workgroup (valid results); 128 = the 4-wave dK/dV kernel instead of the 8-wave one (valid results)
+// 8 = no per-tile barrier in the forward (races: timing only); 16 = forward with one head per workgroup (valid results); 128 = the 4-wave dK/dV kernel instead of the 8-wave one (valid results); 256 / 512 = 8-wave dK/dV without its per-tile barrier / without the K,V fragment reads (timing only)
 
 // Per-lane byte offsets of every fragment read inside one image, computed once: the XOR swizzle depends on the
 // lane only (row blocks of 32 and k-steps of 16 rows leave row&3 and (row>>2)&3 unchanged), so inside the tile
@@ -907,8 +907,8 @@ __global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p
       for (int s = 0; s < 8; ++s) {
         const v8 aq = *reinterpret_cast<const v8*>(smem + ar[s]);
         const v8 ad = *reinterpret_cast<const v8*>(smem + ar[s] + TILE_BYTES);
-        const v8 kfs = *reinterpret_cast<const v8*>(kvs + s * 1024 + lane * 16);
-        const v8 vfs = *reinterpret_cast<const v8*>(kvs + 8192 + s * 1024 + lane * 16);
+        const v8 kfs = (DTA_ABL & 512) ? aq : *reinterpret_cast<const v8*>(kvs + s * 1024 + lane * 16);
+        const v8 vfs = (DTA_ABL & 512) ? ad : *reinterpret_cast<const v8*>(kvs + 8192 + s * 1024 + lane * 16);
         S = T::mma(aq, kfs, S); DP = T::mma(ad, vfs, DP);
       }
       float nl[16], dl[16];
@@ -947,7 +947,7 @@ __global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p
           DV[db] = T::mma(adt, pb, DV[db]); DK[db] = T::mma(aqt, sbf, DK[db]);
         }
       }
-      __syncthreads();
+      if (!(DTA_ABL & 256)) __syncthreads();
       cur ^= 1;
     }
   }
