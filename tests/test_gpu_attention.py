@@ -61,6 +61,7 @@ def _run(plan, se, Hq, Hkv, dtype, seed=0):
     ({"kind": "tau2", "seed": 2, "V": 50, "G": 5, "sys_len": 300, "turns": 4, "lo": 30, "hi": 120, "cap": 2000}, 16, 8, torch.bfloat16),
     ({"kind": "wide", "seed": 1, "V": 1000, "root": 100, "branches": 12, "depth": 400}, 8, 2, torch.float16),
     ({"kind": "config1", "seed": 0, "V": 1000, "prompt": 128, "rollouts": 4, "gen": 128}, 16, 8, torch.float16),
+    ({"kind": "random_tree", "seed": 11, "n_seq": 25, "max_len": 260, "alphabet": 2}, 14, 2, torch.bfloat16),    # odd GQA group (7): one head per workgroup
 ])
 def test_packed_tree_attention_vs_oracle(case, hq, hkv, dtype):
     for order in ("forward", "backward"):
