@@ -70,7 +70,7 @@ def cpu_baseline_worker():
     torch.set_num_threads(threads)
     flags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
     dtype = torch.bfloat16 if ("avx512_bf16" in flags or "amx_bf16" in flags) else torch.float32    # reference dtypes: run.py:122-126
-    case = {"kind": "tau2", "seed": 0, "G": 2, "sys_len": 500, "turns": 3, "lo": 50, "hi": 225, "cap": 4096}
+    case = {"kind": "tau2", "seed": 0, "G": 3, "sys_len": 750, "turns": 3, "lo": 75, "hi": 340, "cap": 6144}
     seqs = [np.asarray(s, dtype=np.int64) for s in synth.make_case(case)]
     w = {k: v.requires_grad_(True) for k, v in mo.init_weights(mo.QWEN3_0P6B, seed=0, dtype=dtype).items()}
     t0 = time.time()
@@ -82,7 +82,7 @@ def cpu_baseline_worker():
     name = "bf16" if dtype == torch.bfloat16 else "fp32 (host has no avx512_bf16/amx)"
     print("CPU_BASELINE " + json.dumps({
         "value": st["n_tokens"] / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-        "sample": f"tau2-shaped call at 1/4 length scale (G=2, sys 500, 3 turns of 50-225): {st['n_sequences']} seqs, "
+        "sample": f"tau2-shaped call at 3/8 length scale (G=3, sys 750, 3 turns of 75-340): {st['n_sequences']} seqs, "
                   f"{st['n_tokens']} tokens, {st['n_tree_tokens']} tree tokens, Qwen3-0.6B {name}, reference push/pop schedule, "
                   f"block_size 2048, {dt:.1f} s",
         "tree_tokens_per_s": st["n_tree_tokens"] / dt}), flush=True)
