@@ -1,35 +1,29 @@
+// DIAGNOSTIC BUILD ONLY (not part of libdta_mi355x.so): the round-1 attention translation unit with its -DDTA_ABL ablation
+// switches and the retired 4-wave dK/dV kernel, kept so that the attribution experiments of DESIGN.md §9 can be re-run:
+//   hipcc --offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -DDTA_ABL=<bits> tree_attn_r1_ablation.hip ../trie_kernels.hip ../logprob_kernels.hip ../elementwise_kernels.hip -o /tmp/libdta_abl.so
+// and select it with DTA_LIB=/tmp/libdta_abl.so.  Results are wrong for most switch values (timing only).
 // Tree attention forward / backward for gfx950 (MI355X, CDNA4).  head_dim = 128, bf16 or f16.
 //
 // One kernel family serves both forms of the reference's "node attends to its ancestor path":
 //   * packed trie (DFS pre-order): key s visible to query t  <=>  s <= t < subtree_end[s]
 //   * stack form (tree_training_engine.py:171-186): subtree_end == NULL, q_offset = start
 //
-// Tiling (wave64, v_mfma_f32_32x32x16, two waves per SIMD everywhere):
-//   fwd / dQ : workgroup = 8 waves = 128 query rows x the TWO query heads of one kv group (4 waves = 128 rows of one
-//              head when the group is odd); each wave owns 32 rows with the QUERY ON THE MFMA LANE (S^T = K.Q^T), so
-//              the softmax row statistics are lane-local and the S^T accumulator is directly the B operand of
-//              O^T += V^T.P^T / dQ^T += K^T.dS^T.  Both heads share the staged 64-key K/V tiles.
-//   dK/dV    : workgroup = 8 waves = 128 keys of one kv head with the KEY ON THE LANE (S = Q.K^T): the two 4-wave groups
-//              own the same keys and split every 64-row query tile; dK^T/dV^T live in 128 accumulator registers per wave
-//              across the whole query sweep (all query heads of the GQA group); the K/V fragments sit in LDS in fragment
-//              order.  Heavy key tiles are cut into split-Q work units whose fp32 slabs a finalize launch sums in order:
-//              no atomics, bitwise reproducible.
-//   Tiles (K/V for fwd, Q/dO for dK/dV) go global -> LDS by LDS-DMA issued from INLINE ASM (dma_* below) into one
-//   XOR-swizzled 256-B-row image that serves BOTH row reads (ds_read_b128) and transposed reads (ds_read_b64_tr_b16);
-//   the dQ kernel stages through registers (issue early, write late).
-//
-// Why inline asm for the DMA: with the builtin, hipcc (ROCm 7.2) waits `vmcnt(0)` for the in-flight prefetch of the
-// NEXT tile in front of LDS reads of the CURRENT one (before the first ds_read when the kernel has a second __shared__
-// object, before the first transposed / float4 read otherwise) - the prefetch was exposed on every tile.  An asm DMA is
-// outside hipcc's bookkeeping (cdna guide 5.7): the only wait is our own `s_waitcnt vmcnt(0)` in front of the
-// tile-end barrier, so a tile's DMA has the whole compute phase of the previous tile to land.
+// Tiling (wave64, v_mfma_f32_32x32x16):
+//   fwd / dQ : workgroup = 4 waves = 128 query rows of one query head; each wave owns 32 rows with the
+//              QUERY ON THE MFMA LANE (S^T = K·Q^T), so the softmax row statistics are lane-local and
+//              the S^T accumulator is directly the B operand of O^T += V^T·P^T / dQ^T += K^T·dS^T.
+//   dK/dV    : workgroup = 4 waves = 128 keys of one kv head; each wave owns 32 keys with the KEY ON
+//              THE LANE (S = Q·K^T), dK^T/dV^T live in 128 accumulator registers per wave across the whole
+//              query sweep (all query heads of the GQA group) -> no cross-workgroup sum, no atomics.
+//   K/V (resp. Q/dO) tiles of 64 rows x 128 cols are staged global -> registers -> LDS (issue early,
+//   write late) into one swizzled 256-B-row image that serves BOTH row reads (ds_read_b128) and
+//   transposed reads (ds_read_b64_tr_b16).
 //
 // Lane maps used here were verified on hardware by tests/micro/mfma_layout_probe.hip.
-// The round-1 ablation switches (-DDTA_ABL) and the retired 4-wave dK/dV kernel live in csrc/diag/ (not built).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include "dta_common.h"
+#include "../../../include/dta.h"
 
 namespace {
 
@@ -154,6 +148,16 @@ constexpr int QK_LDS = 2 * (2 * TILE_BYTES + SE_BYTES);            // double-buf
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
+// Diagnostic ablation switches (-DDTA_ABL=bits; product builds leave them off): 1 = no exp, 2 = no K row reads,
+// 4 = no V transposed reads.  They only exist to attribute time (cdna guide, rule 17); results are wrong when set.
+#ifndef DTA_ABL
+#define DTA_ABL 0
+#endif
+#define DTA_ABL_E(real, fake) ((DTA_ABL & 1) ? (fake) : (real))
+#define DTA_ABL_A(real, fake) ((DTA_ABL & 2) ? (fake) : (real))
+#define DTA_ABL_B(real, fake) ((DTA_ABL & 4) ? (fake) : (real))
+// 8 = no per-tile barrier in the forward (races: timing only); 16 = forward with one head per workgroup (valid results); 128 = the 4-wave dK/dV kernel instead of the 8-wave one (valid results); 256 / 512 = 8-wave dK/dV without its per-tile barrier / without the K,V fragment reads (timing only)
+
 // Per-lane byte offsets of every fragment read inside one image, computed once: the XOR swizzle depends on the
 // lane only (row blocks of 32 and k-steps of 16 rows leave row&3 and (row>>2)&3 unchanged), so inside the tile
 // loop every ds_read is <lane offset register> + <compile-time immediate>.
@@ -185,71 +189,46 @@ template <class V8> __device__ __forceinline__ V8 tr_frag_o(const char* img_r0, 
   return __builtin_bit_cast(V8, both);
 }
 
-// ---- LDS-DMA from inline asm (see the file header for why) ---------------------------------------------------------
-// A wave instruction lands 64 x 16 B = 1 KiB = 4 image rows lane-linearly at M0, so the image's XOR swizzle goes on the
-// per-lane SOURCE chunk.  The global address is <scalar base> + <32-bit per-lane byte offset>: per tile only the base
-// moves.  `s_nop 4` covers a base that was just produced by v_readfirstlane (VALU-written SGPR -> VMEM, 5 wait states),
-// `s_nop 0` the M0 write -> LDS-DMA hazard.  hipcc does not count these loads: DMA_WAIT() before the barrier that
-// publishes the tile is the only thing that orders them.
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(p);
-}
-// pieces {0, 1} of image A (at lds, lds + 1 KiB) and of image B (at lds + TILE_BYTES, + 1 KiB)
-__device__ __forceinline__ void dma_pair2(uint32_t oa0, uint32_t oa1, const void* ba, uint32_t ob0, uint32_t ob1, const void* bb, uint32_t lds) {
-  asm volatile(
-      "s_nop 4\n\t"
-      "s_mov_b32 m0, %6\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %4\n\t"
-      "s_add_u32 m0, %6, 0x4000\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %2, %5\n\t"
-      "s_add_u32 m0, %6, 0x400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %4\n\t"
-      "s_add_u32 m0, %6, 0x4400\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %3, %5"
-      :: "v"(oa0), "v"(oa1), "v"(ob0), "v"(ob1), "s"(ba), "s"(bb), "s"(lds) : "memory", "scc");
-}
-// 64 dwords (row constants of a tile: subtree_end, lse, delta)
-__device__ __forceinline__ void dma_dword(uint32_t off, const void* base, uint32_t lds) {
-  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(off), "s"(base), "s"(lds) : "memory");
-}
-#define DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-
-// Byte offset of this lane's 16-B chunk of image row `row` (rows of `stride` elements of `esz` bytes), swizzled
-__device__ __forceinline__ uint32_t dma_src_off(int row, int img_row, int lane, int64_t stride, int esz) {
-  const int ch = (lane & 15) ^ (((img_row & 3) << 2) | ((img_row >> 2) & 3));
-  return (uint32_t)((row * stride + ch * 8) * (int64_t)esz);
-}
-
-// K/V tile pair of the forward: NW waves move the 16 + 16 pieces; wave w owns pieces (16/NW)*w .. of both images.
-// subtree_end of the 64 keys goes by 4-byte DMA from wave 0; keys at or beyond the run end are excluded by the
-// caller's `k <= min(q, kend-1)` test, not by a sentinel.
+// K/V tile pair global -> LDS by LDS-DMA: NW waves move the 16 + 16 one-KiB pieces (4 image rows each) of the
+// two 64-row images; the image's XOR swizzle goes on the per-lane SOURCE chunk.  Per-lane source offsets
+// (voff_k / voff_v, bytes inside a 64-row tile) are fixed for the whole sweep, so per tile only a scalar base
+// moves (scalar-base + lane-offset DMA form).  subtree_end of the 64 keys goes by 4-byte DMA from wave 0 (an
+// ordinary load + ds_write would park that wave for a memory latency on every tile); keys at or beyond the
+// run end are excluded by the caller's `k <= min(q, kend-1)` test, not by a sentinel.
 #define DTA_KV_OFFSETS(NW)                                                                                 \
   uint32_t voff_k[16 / (NW)], voff_v[16 / (NW)];                                                           \
   _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) {                                               \
-    const int row_ = 4 * (wave * (16 / (NW)) + i_) + (lane >> 4);                                          \
-    voff_k[i_] = dma_src_off(row_, row_, lane, p.kv_st, sizeof(e));                                        \
-    voff_v[i_] = dma_src_off(row_, row_, lane, p.v_st, sizeof(e)); }
+    const int piece_ = wave * (16 / (NW)) + i_, row_ = 4 * piece_ + (lane >> 4);                           \
+    const int ch_ = (lane & 15) ^ (((row_ & 3) << 2) | ((row_ >> 2) & 3));                                  \
+    voff_k[i_] = (uint32_t)((row_ * p.kv_st + ch_ * 8) * (int64_t)sizeof(e));                              \
+    voff_v[i_] = (uint32_t)((row_ * p.v_st + ch_ * 8) * (int64_t)sizeof(e)); }
 #define DTA_KV_DMA(BASE, K0, NW)                                                                           \
   { char* base_ = (BASE); const int k0_ = (K0);                                                            \
     if (wave == 0) {                                                                                       \
       if (p.subtree_end) { int ki_ = k0_ + lane; ki_ = ki_ < p.Tk ? ki_ : p.Tk - 1;                        \
-        dma_dword((uint32_t)ki_ * 4u, p.subtree_end, lds_addr(base_ + 2 * TILE_BYTES)); }                  \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.subtree_end + ki_), \
+                                         (__attribute__((address_space(3))) void*)(base_ + 2 * TILE_BYTES), 4, 0, 0); } \
       else reinterpret_cast<int*>(base_ + 2 * TILE_BYTES)[lane] = 0x7fffffff; }                            \
     const char* kb_ = reinterpret_cast<const char*>(kbase) + (int64_t)k0_ * p.kv_st * (int64_t)sizeof(e);  \
     const char* vb_ = reinterpret_cast<const char*>(vbase) + (int64_t)k0_ * p.v_st * (int64_t)sizeof(e);   \
-    uint32_t ok_[16 / (NW)], ov_[16 / (NW)];                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) { ok_[i_] = voff_k[i_]; ov_[i_] = voff_v[i_]; } \
-    if (k0_ + 64 > p.Tk) {                         /* ragged last tile of the tensor: clamp the row per lane */ \
+    if (k0_ + 64 <= p.Tk) {                                                                                \
       _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) {                                           \
-        const int row_ = 4 * (wave * (16 / (NW)) + i_) + (lane >> 4);                                      \
+        const int piece_ = wave * (16 / (NW)) + i_;                                                        \
+        uint32_t ok_ = voff_k[i_], ov_ = voff_v[i_];                                                       \
+        asm volatile("" : "+v"(ok_), "+v"(ov_));   /* keeps the 32->64-bit extension next to the DMA: scalar-base form */ \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb_ + ok_),       \
+                                         (__attribute__((address_space(3))) void*)(base_ + piece_ * 1024), 16, 0, 0);               \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb_ + ov_),       \
+                                         (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + piece_ * 1024), 16, 0, 0); } \
+    } else {                                       /* ragged last tile of the tensor: clamp the row per lane */ \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) {                                           \
+        const int piece_ = wave * (16 / (NW)) + i_, row_ = 4 * piece_ + (lane >> 4);                       \
+        const int ch_ = (lane & 15) ^ (((row_ & 3) << 2) | ((row_ >> 2) & 3));                              \
         const int rr_ = k0_ + row_ < p.Tk ? row_ : p.Tk - 1 - k0_;                                         \
-        ok_[i_] = dma_src_off(rr_, row_, lane, p.kv_st, sizeof(e)); ov_[i_] = dma_src_off(rr_, row_, lane, p.v_st, sizeof(e)); } } \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); i_ += 2)                                            \
-      dma_pair2(ok_[i_], ok_[i_ + 1], kb_, ov_[i_], ov_[i_ + 1], vb_, lds_addr(base_ + (wave * (16 / (NW)) + i_) * 1024)); }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb_ + ((int64_t)rr_ * p.kv_st + ch_ * 8) * (int64_t)sizeof(e)), \
+                                         (__attribute__((address_space(3))) void*)(base_ + piece_ * 1024), 16, 0, 0);               \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb_ + ((int64_t)rr_ * p.v_st + ch_ * 8) * (int64_t)sizeof(e)),  \
+                                         (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + piece_ * 1024), 16, 0, 0); } } }
 
 // =================================================================================================
 // forward.  HPB = query heads of one kv group handled by a workgroup (waves 4*hb .. 4*hb+3 own head hb);
@@ -301,7 +280,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
   int ck0 = it.k0, ckend = it.kend; bool cmask = it.masked();
   DTA_KV_DMA(smem, it.k0, NW)
   bool has_next = it.advance();
-  DMA_WAIT(); __syncthreads();
+  __syncthreads();                                                 // hipcc drains the DMA (vmcnt(0)) in front of the barrier
 
   // one tile out of buffer BUFI (compile-time): prefetch the next tile into the other buffer, S^T, softmax, PV
 #define FWD_TILE(BUFI)                                                                                     \
@@ -314,7 +293,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                     \
       _Pragma("unroll") for (int g = 0; g < 16; ++g) X[kb][g] = 0.f;                                       \
       _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                        \
-        X[kb] = T::mma(*reinterpret_cast<const v8*>(Ks + 8192 * kb + offs.row[s]), qf[s], X[kb]); \
+        X[kb] = T::mma(DTA_ABL_A(*reinterpret_cast<const v8*>(Ks + 8192 * kb + offs.row[s]), qf[(s + 1) & 7]), qf[s], X[kb]); \
     }                                                                                                      \
     if (cmask) {                                                                                           \
       const int qlim = qidx < ckend ? qidx : ckend - 1;      /* keys at or beyond the run end never count */ \
@@ -343,12 +322,12 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
         _Pragma("unroll") for (int g = 0; g < 16; ++g) O[db][g] *= alpha;                                  \
     }                                                                                                      \
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                       \
-      _Pragma("unroll") for (int g = 0; g < 16; ++g) { const float pv = fast_exp2(__builtin_fmaf(X[kb][g], c, -m)); lsum += pv; X[kb][g] = pv; } \
+      _Pragma("unroll") for (int g = 0; g < 16; ++g) { const float pv = DTA_ABL_E(fast_exp2(__builtin_fmaf(X[kb][g], c, -m)), X[kb][g] * c); lsum += pv; X[kb][g] = pv; } \
     _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                     \
       const v8 pb = pack_half<DT>(X[s4 >> 1], s4 & 1);                                                     \
-      _Pragma("unroll") for (int db = 0; db < 4; ++db) O[db] = T::mma(tr_frag_o<v8>(Vs + 4096 * s4, offs, db), pb, O[db]); \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) O[db] = T::mma(DTA_ABL_B(tr_frag_o<v8>(Vs + 4096 * s4, offs, db), qf[db + s4]), pb, O[db]); \
     }                                                                                                      \
-    DMA_WAIT(); __syncthreads();               /* the next tile has landed in every wave's view */          \
+    if (!(DTA_ABL & 8)) __syncthreads();                                                                   \
     if (!has_next) break;                                                                                  \
     ck0 = nk0_; ckend = nkend_; cmask = nmask_;                                                            \
     has_next = it.advance();                                                                               \
@@ -537,8 +516,275 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
 }
 
 // =================================================================================================
-// backward part 2: dK, dV.  Key tile owns the workgroup.
+// backward part 2: dK, dV.  Key tile owns the workgroup; one wave per SIMD; each wave owns KB blocks of 32
+// keys (KB = 2: 64 keys, 256 accumulator registers), so every Q / dO fragment read from LDS (row-wise
+// for S, dP and transposed for dK^T, dV^T) feeds KB MFMAs.
 // =================================================================================================
+constexpr int KV_LDS = 2 * (2 * TILE_BYTES + 512);                 // double-buffered {Q image, dO image, lse[64], delta[64]}
+
+template <int DT, int KB, int NG>
+__global__ __launch_bounds__(256 * NG) void tree_attn_bwd_dkv_kernel(AttnParams p) {
+  using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
+  constexpr int KT = 128 * KB;
+  __shared__ __attribute__((aligned(16))) char smem_all[NG * KV_LDS];
+
+  // NG = 2: two groups of 4 waves (two waves per SIMD) own the SAME keys and take alternate items of the
+  // (query head, query tile) sweep through their own double-buffered Q/dO images; their partial dK/dV are
+  // summed through LDS at the end in a fixed order.
+  const int tid = threadIdx.x & 255, grp = NG == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform values live in SGPRs: scalar address arithmetic
+  char* smem = smem_all + grp * KV_LDS;
+  const int bid = blockIdx.x;
+  const int kvh = bid % p.Hkv; const int unit = bid / p.Hkv;
+  // a unit = (key tile, packed query range, slab): heavy key tiles (root-side: every query below them sees
+  // them) are cut into several units so that no workgroup carries a serial chain of hundreds of tiles
+  const int kt = p.dkv_units ? p.dkv_units[4 * unit] : unit;
+  const int slab = p.dkv_units ? p.dkv_units[4 * unit + 3] : -1;
+  const int k0 = kt * KT;
+  const int q_hi = p.q_offset + p.Tq;
+  int kidx[KB], se_l[KB];
+  v8 kf[KB][8], vf[KB][8];
+#pragma unroll
+  for (int b = 0; b < KB; ++b) {
+    kidx[b] = k0 + wave * 32 * KB + 32 * b + r;
+    const int kc = kidx[b] < p.Tk ? kidx[b] : p.Tk - 1;
+    int se = (kidx[b] < p.Tk) ? (p.subtree_end ? p.subtree_end[kidx[b]] : 0x7fffffff) : 0;
+    se_l[b] = se < q_hi ? se : q_hi;
+    const e* kp = reinterpret_cast<const e*>(p.k) + (int64_t)kc * p.kv_st + (int64_t)kvh * p.kv_sh;
+    const e* vp = reinterpret_cast<const e*>(p.v) + (int64_t)kc * p.v_st + (int64_t)kvh * p.v_sh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { kf[b][s] = *reinterpret_cast<const v8*>(kp + 16 * s + 8 * h); vf[b][s] = *reinterpret_cast<const v8*>(vp + 16 * s + 8 * h); }
+  }
+  // smallest subtree end over the workgroup's keys: query tiles entirely below it (and below the key tile
+  // itself) need no mask at all
+  __shared__ int se_min_s[4];
+  { int mn = se_l[0];
+#pragma unroll
+    for (int b = 1; b < KB; ++b) mn = se_l[b] < mn ? se_l[b] : mn;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
+    if (lane == 0 && grp == 0) se_min_s[wave] = mn; }
+  __syncthreads();
+  const int se_min = __builtin_amdgcn_readfirstlane(min(min(se_min_s[0], se_min_s[1]), min(se_min_s[2], se_min_s[3])));
+
+  const FragOffs offs = frag_offsets(lane);
+  f32x16 DK[KB][4], DV[KB][4];
+#pragma unroll
+  for (int b = 0; b < KB; ++b)
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) { DK[b][db][g] = 0.f; DV[b][db][g] = 0.f; }
+
+  int qbeg, qend;
+  if (p.dkv_units) { qbeg = __builtin_amdgcn_readfirstlane(p.dkv_units[4 * unit + 1]); qend = __builtin_amdgcn_readfirstlane(p.dkv_units[4 * unit + 2]); }
+  else {
+    qbeg = k0 > p.q_offset ? k0 : p.q_offset;                        // packed index of the first query that can see a key here
+    qend = p.ktile_qend ? p.ktile_qend[kt] : q_hi; qend = qend < q_hi ? qend : q_hi;
+  }
+  const int ntile = qend > qbeg ? (qend - qbeg + 63) / 64 : 0;
+  const int total = ntile * p.group;
+  const float c = p.scale * LOG2E;
+
+  // Q / dO tiles go global -> LDS directly (LDS-DMA, no staging registers, no ds_write): a wave instruction
+  // lands 64 x 16 B = 4 image rows lane-linearly, so the XOR swizzle of the image is applied to the per-lane
+  // SOURCE chunk instead (the read side uses the same involution).  lse / delta are 64 floats each and go by
+  // 4-byte DMA from waves 0 / 1 (an ordinary load + ds_write would stall those waves for a full memory latency per tile).
+  // Per-lane byte offsets of this lane's 16-B chunk inside a 64-row tile are fixed for the whole sweep (piece i of this
+  // wave covers image rows 16*wave + 4*i .. +3); per tile only the UNIFORM base moves, so the DMA takes the
+  // scalar-base + 32-bit-lane-offset form and costs no per-lane address arithmetic in the loop.
+  uint32_t voff_q[4], voff_d[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row_ = 16 * wave + 4 * i + (lane >> 4);
+    const int ch_ = (lane & 15) ^ (((lane >> 4) << 2) | i);              // (row_ & 3) = lane >> 4, (row_ >> 2) & 3 = i
+    voff_q[i] = (uint32_t)((row_ * p.q_st + ch_ * 8) * (int64_t)sizeof(e));
+    voff_d[i] = (uint32_t)((row_ * p.o_st + ch_ * 8) * (int64_t)sizeof(e));
+  }
+#define KV_DMA(HG, TI, B)                                                                                  \
+  { const int hq_ = __builtin_amdgcn_readfirstlane(kvh * p.group + (HG));                                   \
+    const int row0_ = qbeg + 64 * (TI) - p.q_offset;                                                       \
+    char* base_ = smem + (B) * (2 * TILE_BYTES + 512);                                                     \
+    if (wave < 2) { int qr_ = row0_ + lane; qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;   /* wave 0: lse[64], wave 1: delta[64] */ \
+      const float* src_ = (wave == 0 ? p.lse_r : p.delta) + (int64_t)hq_ * p.Tq;                           \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + qr_),        \
+                                       (__attribute__((address_space(3))) void*)(base_ + 2 * TILE_BYTES + wave * 256), 4, 0, 0); } \
+    const char* qb_ = reinterpret_cast<const char*>(p.q) + ((int64_t)hq_ * p.q_sh + (int64_t)row0_ * p.q_st) * (int64_t)sizeof(e);    \
+    const char* db_ = reinterpret_cast<const char*>(p.dout) + ((int64_t)hq_ * p.o_sh + (int64_t)row0_ * p.o_st) * (int64_t)sizeof(e); \
+    if (row0_ + 64 <= p.Tq) {                                                                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
+        uint32_t oq_ = voff_q[i_], od_ = voff_d[i_];                                                       \
+        asm volatile("" : "+v"(oq_), "+v"(od_));   /* keeps the 32->64-bit extension next to the DMA: scalar-base form */ \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb_ + oq_),       \
+                                         (__attribute__((address_space(3))) void*)(base_ + (wave * 4 + i_) * 1024), 16, 0, 0);              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + od_),       \
+                                         (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + (wave * 4 + i_) * 1024), 16, 0, 0); } \
+    } else {                                       /* ragged last tile of the tensor: clamp the row per lane */ \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                   \
+        const int row_ = 16 * wave + 4 * i_ + (lane >> 4);                                                 \
+        const int ch_ = (lane & 15) ^ (((lane >> 4) << 2) | i_);                                           \
+        const int rr_ = row0_ + row_ < p.Tq ? row_ : p.Tq - 1 - row0_;                                     \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb_ + ((int64_t)rr_ * p.q_st + ch_ * 8) * (int64_t)sizeof(e)), \
+                                         (__attribute__((address_space(3))) void*)(base_ + (wave * 4 + i_) * 1024), 16, 0, 0);              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + ((int64_t)rr_ * p.o_st + ch_ * 8) * (int64_t)sizeof(e)), \
+                                         (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + (wave * 4 + i_) * 1024), 16, 0, 0); } } }
+
+  const int niter = (total + NG - 1) / NG;               // same barrier count in every group
+  {
+    int hg_c = 0, ti_c = grp;                        // (query head of the group, query tile) of item idx, advanced without division
+    while (ntile > 0 && ti_c >= ntile) { ti_c -= ntile; ++hg_c; }
+    if (grp < total) KV_DMA(hg_c, ti_c, 0)
+    __syncthreads();                                 // hipcc drains the DMA (vmcnt(0)) in front of the barrier
+    int cur = 0;
+    for (int it_ = 0; it_ < niter; ++it_) {
+      const int idx = it_ * NG + grp;
+      const int ti = ti_c;
+      ti_c += NG;
+      while (ti_c >= ntile) { ti_c -= ntile; ++hg_c; }
+      if (idx + NG < total) KV_DMA(hg_c, ti_c, cur ^ 1)  // buffer cur^1 was last read before the previous barrier
+      if (NG == 1 || idx < total) {
+      const char* Qs = smem + cur * (2 * TILE_BYTES + 512);
+      const float* lse_s = reinterpret_cast<const float*>(Qs + 2 * TILE_BYTES); const float* del_s = lse_s + 64;
+      const int qi0 = qbeg + 64 * ti;                                   // packed index of image row 0
+      const bool full = (qi0 >= k0 + KT - 1) && (qi0 + 63 < se_min);        // workgroup-uniform: no mask needed
+      // one 32-row query block at a time (NOT unrolled: both blocks then share one S/dP register set; unrolled, hipcc
+      // parks a dK/dV tile in VGPRs around the first block, 64 extra accumulator moves per tile)
+#pragma unroll 1
+      for (int qb = 0; qb < 2; ++qb) {
+        // every LDS read below is <address register> + <immediate>: 16 adds of the (buffer, block) base per block
+        const int sb = cur * (2 * TILE_BYTES + 512) + qb * (32 * 256);
+        int ar[8], at[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ar[j] = offs.row[j] + sb; at[j] = offs.tr[j] + sb; }
+        // S and dP start at 0 (inline constant, no register traffic):  p = exp2(c*S - lse),  dS/scale = p*(dP - delta);
+        // the softmax scale of dS is applied once to the dK accumulators in the epilogue
+        f32x16 S[KB], DP[KB];
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) { S[b][g] = 0.f; DP[b][g] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const v8 aq = *reinterpret_cast<const v8*>(smem + ar[s]);
+          const v8 ad = *reinterpret_cast<const v8*>(smem + ar[s] + TILE_BYTES);
+#pragma unroll
+          for (int b = 0; b < KB; ++b) { S[b] = T::mma(aq, kf[b][s], S[b]); DP[b] = T::mma(ad, vf[b][s], DP[b]); }
+        }
+        // row constants come from LDS only now, after the MFMA chains: they occupy registers for the VALU phase alone
+        float nl[16], dl[16];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int ql = 32 * qb + 8 * gq + 4 * h;
+          const float4 l4 = *reinterpret_cast<const float4*>(lse_s + ql);
+          const float4 d4 = *reinterpret_cast<const float4*>(del_s + ql);
+          nl[4 * gq] = l4.x; nl[4 * gq + 1] = l4.y; nl[4 * gq + 2] = l4.z; nl[4 * gq + 3] = l4.w;
+          dl[4 * gq] = d4.x; dl[4 * gq + 1] = d4.y; dl[4 * gq + 2] = d4.z; dl[4 * gq + 3] = d4.w;
+        }
+        if (full) {
+#pragma unroll
+          for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+              const float pv = fast_exp2(__builtin_fmaf(S[b][g], c, -nl[g]));
+              S[b][g] = pv;
+              DP[b][g] = pv * (DP[b][g] - dl[g]);
+            }
+        } else {
+#pragma unroll
+          for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+              const int qi = qi0 + 32 * qb + 8 * (g >> 2) + 4 * h + (g & 3);
+              const bool ok = (kidx[b] <= qi) && (qi < se_l[b]);
+              const float pv = ok ? fast_exp2(__builtin_fmaf(S[b][g], c, -nl[g])) : 0.f;
+              S[b][g] = pv;
+              DP[b][g] = pv * (DP[b][g] - dl[g]);
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          v8 pb[KB], sb[KB];
+#pragma unroll
+          for (int b = 0; b < KB; ++b) { pb[b] = pack_half<DT>(S[b], s2); sb[b] = pack_half<DT>(DP[b], s2); }
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            const v8 adt = tr_pair<v8>(smem + at[db] + TILE_BYTES + 4096 * s2, smem + at[4 + db] + TILE_BYTES + 4096 * s2);
+            const v8 aqt = tr_pair<v8>(smem + at[db] + 4096 * s2, smem + at[4 + db] + 4096 * s2);
+#pragma unroll
+            for (int b = 0; b < KB; ++b) { DV[b][db] = T::mma(adt, pb[b], DV[b][db]); DK[b][db] = T::mma(aqt, sb[b], DK[b][db]); }
+          }
+        }
+      }
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+#undef KV_DMA
+  if (NG == 2) {
+    // group 1 hands its partial sums to group 0 through LDS, 32 accumulators (one d-block of dK and dV) at a time
+    float* red = reinterpret_cast<float*>(smem_all);
+#pragma unroll
+    for (int b = 0; b < KB; ++b)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        if (grp == 1) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) { red[g * 256 + tid] = DK[b][db][g]; red[(16 + g) * 256 + tid] = DV[b][db][g]; }
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) { DK[b][db][g] += red[g * 256 + tid]; DV[b][db][g] += red[(16 + g) * 256 + tid]; }
+        }
+        __syncthreads();
+      }
+    if (grp == 1) return;
+  }
+#pragma unroll
+  for (int b = 0; b < KB; ++b)
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) DK[b][db][g] *= p.scale;
+#pragma unroll
+  for (int b = 0; b < KB; ++b) {
+    const int kloc = wave * 32 * KB + 32 * b + r;
+    if (slab >= 0) {
+      // partial sums of a split key tile: fp32 slab [2][KT keys][128 d], summed in unit order by the finalize kernel
+      float* ws = p.dkv_ws + ((int64_t)slab * p.Hkv + kvh) * (2 * KT * 128) + (int64_t)kloc * 128;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int d = 32 * db + 8 * gq + 4 * h;
+          *reinterpret_cast<float4*>(ws + d) = make_float4(DK[b][db][4 * gq], DK[b][db][4 * gq + 1], DK[b][db][4 * gq + 2], DK[b][db][4 * gq + 3]);
+          *reinterpret_cast<float4*>(ws + KT * 128 + d) = make_float4(DV[b][db][4 * gq], DV[b][db][4 * gq + 1], DV[b][db][4 * gq + 2], DV[b][db][4 * gq + 3]);
+        }
+    } else if (kidx[b] < p.Tk) {
+      e* dkp = reinterpret_cast<e*>(p.dk) + (int64_t)kidx[b] * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+      e* dvp = reinterpret_cast<e*>(p.dv) + (int64_t)kidx[b] * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int d = 32 * db + 8 * gq + 4 * h;
+          v4 wk, wv;
+          if (p.accumulate) {
+            const v4 ok_ = *reinterpret_cast<const v4*>(dkp + d); const v4 ov_ = *reinterpret_cast<const v4*>(dvp + d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wk[j] = (e)(DK[b][db][4 * gq + j] + (float)ok_[j]); wv[j] = (e)(DV[b][db][4 * gq + j] + (float)ov_[j]); }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wk[j] = (e)DK[b][db][4 * gq + j]; wv[j] = (e)DV[b][db][4 * gq + j]; }
+          }
+          *reinterpret_cast<v4*>(dkp + d) = wk;
+          *reinterpret_cast<v4*>(dvp + d) = wv;
+        }
+    }
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // dK/dV with TWO waves per SIMD (8 waves): the two wave groups own the same 128 keys and split every 64-row query tile
 // between them (group g takes rows 32g..32g+31), so they share ONE double-buffered Q/dO image.  To fit 256 registers
@@ -547,7 +793,7 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
 // -------------------------------------------------------------------------------------------------
 constexpr int KV2_FRAGS = 4 * 16384;                                // 4 key slots x {K: 8 fragments x 1 KiB, V: 8 x 1 KiB}
 constexpr int KV2_BUF = 2 * TILE_BYTES + 512;
-constexpr int KV2_LDS = KV2_FRAGS + 2 * KV2_BUF + 16;                   // + se_min[4]: ONE __shared__ object (a second one makes hipcc drain vmcnt in front of every LDS read)
+constexpr int KV2_LDS = KV2_FRAGS + 2 * KV2_BUF;
 
 template <int DT>
 __global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p) {
@@ -579,7 +825,7 @@ __global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p
         *reinterpret_cast<v8*>(kvs + 8192 + s * 1024 + lane * 16) = *reinterpret_cast<const v8*>(vp + 16 * s + 8 * h);
       }
     } }
-  int* se_min_s = reinterpret_cast<int*>(smem_all + KV2_FRAGS + 2 * KV2_BUF);
+  __shared__ int se_min_s[4];
   { int mn = se_l;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
@@ -604,48 +850,53 @@ __global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p
   const int total = ntile * p.group;
   const float c = p.scale * LOG2E;
 
-  // tile DMA: 16 one-KiB pieces per image over 8 waves = 2 per wave per image (piece = 2*wave8 + i: rows 8*wave8 + 4*i ..);
-  // lse / delta rows (64 floats each) by 4-byte DMA from waves 0 / 1.
+  // tile DMA: 16 one-KiB pieces per image over 8 waves = 2 per wave per image (piece = 2*wave8 + i: rows 8*wave8 + 4*i ..)
   uint32_t voff_q[2], voff_d[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row_ = 8 * wave8 + 4 * i + (lane >> 4);
-    voff_q[i] = dma_src_off(row_, row_, lane, p.q_st, sizeof(e));
-    voff_d[i] = dma_src_off(row_, row_, lane, p.o_st, sizeof(e));
+    const int ch_ = (lane & 15) ^ (((row_ & 3) << 2) | ((row_ >> 2) & 3));
+    voff_q[i] = (uint32_t)((row_ * p.q_st + ch_ * 8) * (int64_t)sizeof(e));
+    voff_d[i] = (uint32_t)((row_ * p.o_st + ch_ * 8) * (int64_t)sizeof(e));
   }
-  const uint32_t lds_tiles = lds_addr(smem);
-  // scalar cursor of the NEXT tile to stage: byte offsets of its first row in q / dout and float offset of its row
-  // constants; advanced by additions (64 rows down, or to row qbeg of the next query head) - no 64-bit multiplies per tile
-  const int64_t q_step = 64 * p.q_st * (int64_t)sizeof(e), d_step = 64 * p.o_st * (int64_t)sizeof(e);
-  const int64_t q_wrap = p.q_sh * (int64_t)sizeof(e) - ntile * q_step, d_wrap = p.o_sh * (int64_t)sizeof(e) - ntile * d_step;
-  int64_t q_cur = ((int64_t)(kvh * p.group) * p.q_sh + (int64_t)(qbeg - p.q_offset) * p.q_st) * (int64_t)sizeof(e);
-  int64_t d_cur = ((int64_t)(kvh * p.group) * p.o_sh + (int64_t)(qbeg - p.q_offset) * p.o_st) * (int64_t)sizeof(e);
-  int64_t c_cur = (int64_t)(kvh * p.group) * p.Tq;
-  int row_n = qbeg - p.q_offset, ti_n = 0;
-#define KV2_DMA(B)                                                                                         \
-  { const uint32_t lb_ = lds_tiles + (uint32_t)(B) * KV2_BUF;                                              \
-    if (wave8 < 2) { int qr_ = row_n + lane; qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;   /* wave 0: lse[64], wave 1: delta[64] */ \
-      dma_dword((uint32_t)qr_ * 4u, (wave8 == 0 ? p.lse_r : p.delta) + c_cur, lb_ + 2 * TILE_BYTES + wave8 * 256); } \
-    uint32_t oq0_ = voff_q[0], oq1_ = voff_q[1], od0_ = voff_d[0], od1_ = voff_d[1];                       \
-    if (row_n + 64 > p.Tq) {                       /* ragged last tile of the tensor: clamp the row per lane */ \
-      const int ra_ = 8 * wave8 + (lane >> 4), rb_ = ra_ + 4;                                              \
-      const int ca_ = row_n + ra_ < p.Tq ? ra_ : p.Tq - 1 - row_n, cb_ = row_n + rb_ < p.Tq ? rb_ : p.Tq - 1 - row_n; \
-      oq0_ = dma_src_off(ca_, ra_, lane, p.q_st, sizeof(e)); oq1_ = dma_src_off(cb_, rb_, lane, p.q_st, sizeof(e)); \
-      od0_ = dma_src_off(ca_, ra_, lane, p.o_st, sizeof(e)); od1_ = dma_src_off(cb_, rb_, lane, p.o_st, sizeof(e)); } \
-    dma_pair2(oq0_, oq1_, reinterpret_cast<const char*>(p.q) + q_cur, od0_, od1_, reinterpret_cast<const char*>(p.dout) + d_cur, lb_ + wave8 * 2048); \
-    ++ti_n; row_n += 64; q_cur += q_step; d_cur += d_step;                                                 \
-    if (ti_n >= ntile) { ti_n = 0; row_n = qbeg - p.q_offset; q_cur += q_wrap; d_cur += d_wrap; c_cur += p.Tq; } }
+#define KV2_DMA(HG, TI, B)                                                                                 \
+  { const int hq_ = __builtin_amdgcn_readfirstlane(kvh * p.group + (HG));                                   \
+    const int row0_ = qbeg + 64 * (TI) - p.q_offset;                                                       \
+    char* base_ = smem + (B) * KV2_BUF;                                                                    \
+    if (wave8 < 2) { int qr_ = row0_ + lane; qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;   /* wave 0: lse[64], wave 1: delta[64] */ \
+      const float* src_ = (wave8 == 0 ? p.lse_r : p.delta) + (int64_t)hq_ * p.Tq;                          \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + qr_),        \
+                                       (__attribute__((address_space(3))) void*)(base_ + 2 * TILE_BYTES + wave8 * 256), 4, 0, 0); } \
+    const char* qb_ = reinterpret_cast<const char*>(p.q) + ((int64_t)hq_ * p.q_sh + (int64_t)row0_ * p.q_st) * (int64_t)sizeof(e);    \
+    const char* db_ = reinterpret_cast<const char*>(p.dout) + ((int64_t)hq_ * p.o_sh + (int64_t)row0_ * p.o_st) * (int64_t)sizeof(e); \
+    if (row0_ + 64 <= p.Tq) {                                                                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                   \
+        uint32_t oq_ = voff_q[i_], od_ = voff_d[i_];                                                       \
+        asm volatile("" : "+v"(oq_), "+v"(od_));                                                           \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb_ + oq_),       \
+                                         (__attribute__((address_space(3))) void*)(base_ + (wave8 * 2 + i_) * 1024), 16, 0, 0);              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + od_),       \
+                                         (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + (wave8 * 2 + i_) * 1024), 16, 0, 0); } \
+    } else {                                       /* ragged last tile of the tensor: clamp the row per lane */ \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                   \
+        const int row_ = 8 * wave8 + 4 * i_ + (lane >> 4);                                                 \
+        const int ch_ = (lane & 15) ^ (((row_ & 3) << 2) | ((row_ >> 2) & 3));                              \
+        const int rr_ = row0_ + row_ < p.Tq ? row_ : p.Tq - 1 - row0_;                                     \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb_ + ((int64_t)rr_ * p.q_st + ch_ * 8) * (int64_t)sizeof(e)), \
+                                         (__attribute__((address_space(3))) void*)(base_ + (wave8 * 2 + i_) * 1024), 16, 0, 0);              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db_ + ((int64_t)rr_ * p.o_st + ch_ * 8) * (int64_t)sizeof(e)), \
+                                         (__attribute__((address_space(3))) void*)(base_ + TILE_BYTES + (wave8 * 2 + i_) * 1024), 16, 0, 0); } } }
 
   {
-    int ti_c = 0;
-    if (total > 0) KV2_DMA(0)
-    DMA_WAIT(); __syncthreads();
+    int hg_c = 0, ti_c = 0;
+    if (total > 0) KV2_DMA(hg_c, ti_c, 0)
+    __syncthreads();
     int cur = 0;
     for (int idx = 0; idx < total; ++idx) {
       const int ti = ti_c;
       ti_c += 1;
-      if (ti_c >= ntile) ti_c = 0;
-      if (idx + 1 < total) KV2_DMA(cur ^ 1)                  // lands while this tile computes; waited for at the tile end
+      if (ti_c >= ntile) { ti_c = 0; ++hg_c; }
+      if (idx + 1 < total) KV2_DMA(hg_c, ti_c, cur ^ 1)
       const float* lse_s = reinterpret_cast<const float*>(smem + cur * KV2_BUF + 2 * TILE_BYTES); const float* del_s = lse_s + 64;
       const int qi0 = qbeg + 64 * ti + 32 * grp;                       // packed index of this group's first row
       const bool full = (qbeg + 64 * ti >= k0 + KT - 1) && (qbeg + 64 * ti + 63 < se_min);   // workgroup-uniform: no mask needed
@@ -660,8 +911,8 @@ __global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p
       for (int s = 0; s < 8; ++s) {
         const v8 aq = *reinterpret_cast<const v8*>(smem + ar[s]);
         const v8 ad = *reinterpret_cast<const v8*>(smem + ar[s] + TILE_BYTES);
-        const v8 kfs = *reinterpret_cast<const v8*>(kvs + s * 1024 + lane * 16);
-        const v8 vfs = *reinterpret_cast<const v8*>(kvs + 8192 + s * 1024 + lane * 16);
+        const v8 kfs = (DTA_ABL & 512) ? aq : *reinterpret_cast<const v8*>(kvs + s * 1024 + lane * 16);
+        const v8 vfs = (DTA_ABL & 512) ? ad : *reinterpret_cast<const v8*>(kvs + 8192 + s * 1024 + lane * 16);
         S = T::mma(aq, kfs, S); DP = T::mma(ad, vfs, DP);
       }
       float nl[16], dl[16];
@@ -700,7 +951,7 @@ __global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p
           DV[db] = T::mma(adt, pb, DV[db]); DK[db] = T::mma(aqt, sbf, DK[db]);
         }
       }
-      DMA_WAIT(); __syncthreads();
+      if (!(DTA_ABL & 256)) __syncthreads();
       cur ^= 1;
     }
   }
@@ -822,8 +1073,8 @@ extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v,
   p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.v_st = v_st; p.v_sh = v_sh; p.o_st = o_st; p.o_sh = o_sh; p.scale = scale;
   const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  DTA_REFUSE_IF_PRIOR_ERROR();
-  if (p.group % 2 == 0) {      // two query heads of a kv group share the staged K/V tiles
+  (void)hipGetLastError();   // drop a stale error of an earlier, unrelated runtime call
+  if (p.group % 2 == 0 && !(DTA_ABL & 16)) {      // two query heads of a kv group share the staged K/V tiles
     dim3 grid(nqt * Hq / 2), block(512);
     if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_BF16, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_F16, 2>), grid, block, 0, st, p);
@@ -832,7 +1083,7 @@ extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v,
     if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_BF16, 1>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_F16, 1>), grid, block, 0, st, p);
   }
-  return DTA_LAUNCH_STATUS();
+  return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
 }
 
 extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout,
@@ -860,25 +1111,31 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.v_st = v_st; p.v_sh = v_sh; p.o_st = o_st; p.o_sh = o_sh;
   p.dq_st = dq_st; p.dq_sh = dq_sh; p.dkv_st = dkv_st; p.dkv_sh = dkv_sh; p.scale = scale; p.accumulate = accumulate;
   const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
+  // KB = 2 (64 keys per wave, every LDS fragment feeding two MFMAs) is written but needs > 512 registers
+  // with K and V fragments resident; it stays out of the build until their staging moves to LDS/DMA.
   p.ktile = DTA_KTILE;
   const int nkt = (Tk + p.ktile - 1) / p.ktile;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  DTA_REFUSE_IF_PRIOR_ERROR();
+  (void)hipGetLastError();   // drop a stale error of an earlier, unrelated runtime call
   if ((which & 7) == 0) return DTA_EINVAL;
   const bool fin = ((which & 2) && !(which & 8)) || (which & 4);     // slab finalize: with the dK/dV launch unless bit3, or alone (bit2)
+  // NG = 2 (two wave groups, two waves per SIMD) was measured at 0.52x the speed of NG = 1 on the tau2 trie: 128
+  // accumulators + 64 K/V fragment registers do not fit 256 registers per wave (69 spills).  Not instantiated.
   const int ndkv = dkv_units ? n_units : nkt;
   const bool pair = p.group % 2 == 0;
   const dim3 gq(pair ? nqt * Hq / 2 : nqt * Hq), bq(pair ? 512 : 256);
   if (dtype == DTA_BF16) {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 1>), gq, bq, 0, st, p); }
-    if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv2_kernel<DTA_BF16>), dim3(ndkv * Hkv), dim3(512), 0, st, p);
+    if (which & 2) { if (!(DTA_ABL & 128)) hipLaunchKernelGGL((tree_attn_bwd_dkv2_kernel<DTA_BF16>), dim3(ndkv * Hkv), dim3(512), 0, st, p);
+                     else hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_BF16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p); }
     if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_BF16>, dim3(n_splits * Hkv, FIN_SPLIT), dim3(256), 0, st, p);
   } else {
     if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 1>), gq, bq, 0, st, p); }
-    if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv2_kernel<DTA_F16>), dim3(ndkv * Hkv), dim3(512), 0, st, p);
+    if (which & 2) { if (!(DTA_ABL & 128)) hipLaunchKernelGGL((tree_attn_bwd_dkv2_kernel<DTA_F16>), dim3(ndkv * Hkv), dim3(512), 0, st, p);
+                     else hipLaunchKernelGGL((tree_attn_bwd_dkv_kernel<DTA_F16, DTA_KTILE / 128, 1>), dim3(ndkv * Hkv), dim3(256), 0, st, p); }
     if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_F16>, dim3(n_splits * Hkv, FIN_SPLIT), dim3(256), 0, st, p);
   }
-  return DTA_LAUNCH_STATUS();
+  return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
 }
 
 // Token-major convenience forms declared in dta.h: head stride = 128 elements.

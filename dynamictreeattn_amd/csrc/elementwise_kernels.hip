@@ -2,12 +2,12 @@
 //   dta_rmsnorm_fwd/bwd        y = w · cast(x · rsqrt(mean(x²)+eps))                 (Qwen3RMSNorm arithmetic)
 //   dta_qk_norm_rope_fwd/bwd   per (token, head) of 128: optional RMSNorm, then RoPE at position = trie depth
 //   dta_swiglu_fwd/bwd         y = cast(silu(g)) · u
-// These replace ~40 torch elementwise launches per layer (fp32 up-casts included) that made 28 % of the
-// first profiled step (profiles/r1_v0_bench_kernel_stats.csv).  Reference call sites: the model call of
+// These replace ~40 torch elementwise launches per layer (fp32 up-casts included); together they are ~18 ms of a
+// 250 ms step (profiles/r1_bench_kernel_stats.csv).  Reference call sites: the model call of
 // tree_training_engine.py:182-186, 248-252, 351-353 (third-party transformers Qwen3 layers).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/dta.h"
+#include "dta_common.h"
 
 namespace {
 
@@ -24,7 +24,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// RMSNorm over rows of H (H % 8 == 0, H <= 8192).  One wave per row, 4 rows per workgroup, grid-stride.
+// RMSNorm over rows of H (H % 8 == 0; forward: any H, backward: H <= 8192).  One wave per row, 4 rows per workgroup, grid-stride.
 // ---------------------------------------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* __restrict__ x_, const void* __restrict__ delta_, const void* __restrict__ w_,
@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* __restrict
   }
 }
 
-// dx = r·(dt − t̂·mean(dt·t̂)), dt = dy·w, t̂ = x·r ;  dw partial per workgroup: Σ_rows dy·t̂  (H <= 4096 -> <= 8 x v8 per lane)
-template <int DT>
+// dx = r·(dt − t̂·mean(dt·t̂)), dt = dy·w, t̂ = x·r ;  dw partial per workgroup: Σ_rows dy·t̂.
+// NA = v8 groups per lane held in registers: 8 (H <= 4096) or 16 (H <= 8192: Qwen3-14B/32B hidden 5120).
+template <int DT, int NA>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_, const void* __restrict__ dy_,
                                                           const void* __restrict__ dres_,
                                                           const float* __restrict__ rstd, void* __restrict__ dx_, float* __restrict__ dw_part,
@@ -82,10 +83,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const e* w = reinterpret_cast<const e*>(w_);
   const int nv = H >> 3;
-  const int per_lane = (nv + 63) >> 6;                      // <= 8
-  float acc[8][8];
+  const int per_lane = (nv + 63) >> 6;                      // <= NA
+  float acc[NA][8];
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[a][j] = 0.f;
   for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict
     const float r = rstd[row];
     float dot = 0.f;
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
+    for (int a = 0; a < NA; ++a) {
       const int i = lane + 64 * a;
       if (a < per_lane && i < nv) {
         const v8 v = *reinterpret_cast<const v8*>(x + 8 * i); const v8 g = *reinterpret_cast<const v8*>(dy + 8 * i);
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict
     }
     dot = wave_sum(dot) / (float)H;
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
+    for (int a = 0; a < NA; ++a) {
       const int i = lane + 64 * a;
       if (a < per_lane && i < nv) {
         const v8 v = *reinterpret_cast<const v8*>(x + 8 * i); const v8 g = *reinterpret_cast<const v8*>(dy + 8 * i);
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict
   // reduce the 4 waves' dw partials through LDS, one v8-group at a time
   float* out = dw_part + (int64_t)blockIdx.x * H;
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {                              // static register index; `a < per_lane` is block-uniform
+  for (int a = 0; a < NA; ++a) {                              // static register index; `a < per_lane` is block-uniform
     if (a < per_lane) {
       __syncthreads();
 #pragma unroll
@@ -294,15 +295,15 @@ inline int row_blocks(int64_t rows, int per_block, int cap) { int64_t b = (rows 
 }  // namespace
 
 #define DTA_DISPATCH(KERNEL, GRID, ...)                                                                    \
-  do { hipStream_t st_ = static_cast<hipStream_t>(stream); (void)hipGetLastError();                       \
+  do { hipStream_t st_ = static_cast<hipStream_t>(stream); DTA_REFUSE_IF_PRIOR_ERROR();                    \
        if (dtype == DTA_BF16) hipLaunchKernelGGL(KERNEL<DTA_BF16>, dim3(GRID), dim3(256), 0, st_, __VA_ARGS__); \
        else hipLaunchKernelGGL(KERNEL<DTA_F16>, dim3(GRID), dim3(256), 0, st_, __VA_ARGS__);               \
-       return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH; } while (0)
+       return DTA_LAUNCH_STATUS(); } while (0)
 
 extern "C" int dta_rmsnorm_fwd(const void* x, const void* delta, const void* w, void* x_out, void* y, float* rstd,
                                int32_t R, int32_t H, float eps, int32_t dtype, void* stream) {
   if (!x || !w || !y || !rstd || R <= 0 || H <= 0 || ((delta != nullptr) != (x_out != nullptr))) return DTA_EINVAL;
-  if ((dtype != DTA_BF16 && dtype != DTA_F16) || H % 8 || H > 4096) return DTA_EUNSUPPORTED;
+  if ((dtype != DTA_BF16 && dtype != DTA_F16) || H % 8) return DTA_EUNSUPPORTED;
   if (!al16(x) || !al16(w) || !al16(y) || (delta && (!al16(delta) || !al16(x_out)))) return DTA_EALIGN;
   DTA_DISPATCH(rmsnorm_fwd_kernel, row_blocks(R, 4, 4096), x, delta, w, x_out, y, rstd, R, H, eps);
 }
@@ -312,9 +313,19 @@ extern "C" int dta_rmsnorm_bwd_blocks(int32_t R) { return row_blocks(R, 4, 512);
 extern "C" int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dres, const float* rstd, void* dx, float* dw_partial,
                                int32_t R, int32_t H, int32_t dtype, void* stream) {
   if (!x || !w || !dy || !rstd || !dx || !dw_partial || R <= 0 || H <= 0) return DTA_EINVAL;
-  if ((dtype != DTA_BF16 && dtype != DTA_F16) || H % 8 || H > 4096) return DTA_EUNSUPPORTED;
+  if ((dtype != DTA_BF16 && dtype != DTA_F16) || H % 8 || H > 8192) return DTA_EUNSUPPORTED;
   if (!al16(x) || !al16(w) || !al16(dy) || !al16(dx) || (dres && !al16(dres))) return DTA_EALIGN;
-  DTA_DISPATCH(rmsnorm_bwd_kernel, row_blocks(R, 4, 512), x, w, dy, dres, rstd, dx, dw_partial, R, H);
+  hipStream_t st_ = static_cast<hipStream_t>(stream);
+  DTA_REFUSE_IF_PRIOR_ERROR();
+  const dim3 grid(row_blocks(R, 4, 512)), block(256);
+  if (H <= 4096) {
+    if (dtype == DTA_BF16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_BF16, 8>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
+    else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F16, 8>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
+  } else {
+    if (dtype == DTA_BF16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_BF16, 16>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
+    else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F16, 16>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
+  }
+  return DTA_LAUNCH_STATUS();
 }
 
 extern "C" int dta_qk_norm_rope_fwd(const void* x, const void* w, const float* cos_sin, void* y, float* rstd,

@@ -1,22 +1,26 @@
 // Fused log-softmax statistics over vocabulary rows for gfx950 — HBM-bound, one pass per direction.
-//   fwd: per row r of logits[R, V] (bf16/f16): lse[r] = ln Σ exp(x/T), ent[r] = lse − Σ p·x/T,
+//   fwd: per row r of logits[R, V] (bf16 / f16 / f32): lse[r] = ln Σ exp(x/T), ent[r] = lse − Σ p·x/T,
 //        lp[r] = x[label[r]]/T − lse[r]                       (vocab_parallel.py:13-27 arithmetic, fp32)
-//   bwd: logits are overwritten IN PLACE by d(loss)/d(logits):
-//        g[r,j] = ( p_j·(−G[r] + ge[r]·(lse[r] − ent[r] − x_j/T)) + glp[r]·[j == label[r]] ) / T
-//        where G[r] = glp[r] + gextra[r] is the summed gradient of every log-prob picked from row r
-//        (a fork node has one picked token per child; the extra one-hot terms are added by the caller).
+//        and, for every EXTRA label e of the row (CSR extra_ptr/extra_labels: a fork node of the trie predicts one token per
+//        child, tree_training_engine.py:205-209, 217-220, 369-372), extra_lp[e] = x[extra_labels[e]]/T − lse[r].
+//   bwd: dLoss/dlogits, written to `out` (out == logits: in place):
+//        g[r,j] = ( p_j·(−G[r] + ge[r]·(lse[r] − ent[r] − x_j/T)) + Σ_{picked j} g_picked ) / T
+//        where G[r] = glp[r] + Σ_e g_extra_lp[e] is the summed gradient of every log-prob picked from row r.
 // One 256-thread workgroup per row, 16-byte loads, online (max, Σexp, Σexp·x) per lane, block reduce.
+// Algorithmic HBM bytes: fwd V·sizeof(e) per row (one read); bwd 2·V·sizeof(e) per row (one read, one write).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/dta.h"
+#include "dta_common.h"
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 template <int DT> struct LTy;
 template <> struct LTy<DTA_BF16> { using e = __bf16; using v8 = bf16x8; };
 template <> struct LTy<DTA_F16> { using e = _Float16; using v8 = f16x8; };
+template <> struct LTy<DTA_F32> { using e = float; using v8 = f32x8; };
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -43,15 +47,19 @@ __device__ __forceinline__ Stat block_reduce(Stat v, Stat* sh) {
   return r;
 }
 
+struct FwdArgs {
+  const void* logits; const int64_t* labels; const int32_t* extra_ptr; const int64_t* extra_labels;
+  float *lse, *ent, *lp, *extra_lp, *stats;
+  int R, V; int64_t stride; float inv_temp;
+};
+
 template <int DT>
-__global__ __launch_bounds__(256) void logprob_entropy_fwd_kernel(const void* __restrict__ logits_, const int64_t* __restrict__ labels,
-                                                                  float* __restrict__ lse, float* __restrict__ ent, float* __restrict__ lp,
-                                                                  float* __restrict__ stats, int R, int V, int64_t stride, float inv_temp) {
+__global__ __launch_bounds__(256) void logprob_entropy_fwd_kernel(FwdArgs a) {
   using e = typename LTy<DT>::e; using v8 = typename LTy<DT>::v8;
   __shared__ Stat sh[4];
-  const int row = blockIdx.x;
-  const e* x = reinterpret_cast<const e*>(logits_) + (int64_t)row * stride;
-  const float k = LOG2E * inv_temp;
+  const int row = blockIdx.x, V = a.V;
+  const e* x = reinterpret_cast<const e*>(a.logits) + (int64_t)row * a.stride;
+  const float k = LOG2E * a.inv_temp;
   Stat st{-1e30f, 0.f, 0.f};
   const int nv = V >> 3;
   for (int i = threadIdx.x; i < nv; i += 256) {
@@ -72,35 +80,48 @@ __global__ __launch_bounds__(256) void logprob_entropy_fwd_kernel(const void* __
     st = Stat{m, st.s * f + p, __builtin_fmaf(p, y, st.t * f)};
   }
   st = block_reduce(st, sh);
-  if (threadIdx.x == 0 && stats) {
-    // vocab-sharded use: raw per-shard statistics (log2 domain of the scaled logits) for a cross-rank combine
-    const int64_t lab = labels ? labels[row] : -1;
-    stats[4 * row] = st.m; stats[4 * row + 1] = st.s; stats[4 * row + 2] = st.t;
-    stats[4 * row + 3] = (lab >= 0 && lab < V) ? (float)x[lab] * inv_temp : 0.f;
-  } else if (threadIdx.x == 0) {
-    const float lse2 = st.m + __builtin_amdgcn_logf(st.s);               // log2 domain
-    const float l = lse2 * LN2;
-    lse[row] = l;
-    if (ent) ent[row] = l - (st.t / st.s) * LN2;                         // H = lse − E[x/T]
-    if (lp) { const int64_t lab = labels[row]; lp[row] = (lab >= 0 && lab < V) ? (float)x[lab] * inv_temp - l : 0.f; }
+  const int e0 = a.extra_ptr ? a.extra_ptr[row] : 0, e1 = a.extra_ptr ? a.extra_ptr[row + 1] : 0;
+  if (a.stats) {
+    // vocab-sharded use: raw per-shard statistics (log2 domain of the scaled logits) for a cross-rank combine; picked
+    // values are the raw x/T of the labels this shard owns (0 otherwise)
+    if (threadIdx.x == 0) {
+      const int64_t lab = a.labels ? a.labels[row] : -1;
+      a.stats[4 * row] = st.m; a.stats[4 * row + 1] = st.s; a.stats[4 * row + 2] = st.t;
+      a.stats[4 * row + 3] = (lab >= 0 && lab < V) ? (float)x[lab] * a.inv_temp : 0.f;
+    }
+    for (int f = e0 + threadIdx.x; f < e1; f += 256) { const int64_t lab = a.extra_labels[f]; a.extra_lp[f] = (lab >= 0 && lab < V) ? (float)x[lab] * a.inv_temp : 0.f; }
+  } else {
+    const float l = (st.m + __builtin_amdgcn_logf(st.s)) * LN2;          // v_log_f32 = log2
+    if (threadIdx.x == 0) {
+      a.lse[row] = l;
+      if (a.ent) a.ent[row] = l - (st.t / st.s) * LN2;                    // H = lse − E[x/T]
+      if (a.lp) { const int64_t lab = a.labels[row]; a.lp[row] = (lab >= 0 && lab < V) ? (float)x[lab] * a.inv_temp - l : 0.f; }
+    }
+    for (int f = e0 + threadIdx.x; f < e1; f += 256) { const int64_t lab = a.extra_labels[f]; a.extra_lp[f] = (lab >= 0 && lab < V) ? (float)x[lab] * a.inv_temp - l : 0.f; }
   }
 }
 
+struct BwdArgs {
+  const void* logits; void* out; const int64_t* labels; const int32_t* extra_ptr; const int64_t* extra_labels;
+  const float *lse, *ent, *glp, *gextra, *gent;
+  int R, V; int64_t stride, out_stride; float inv_temp;
+};
+
 template <int DT>
-__global__ __launch_bounds__(256) void logprob_entropy_bwd_kernel(void* __restrict__ logits_, const int64_t* __restrict__ labels,
-                                                                  const float* __restrict__ lse, const float* __restrict__ ent,
-                                                                  const float* __restrict__ glp, const float* __restrict__ gextra,
-                                                                  const float* __restrict__ gent,
-                                                                  int R, int V, int64_t stride, float inv_temp) {
+__global__ __launch_bounds__(256) void logprob_entropy_bwd_kernel(BwdArgs b) {
   using e = typename LTy<DT>::e; using v8 = typename LTy<DT>::v8;
-  const int row = blockIdx.x;
-  e* x = reinterpret_cast<e*>(logits_) + (int64_t)row * stride;
-  const float l = lse[row];
-  const float ge = gent ? gent[row] : 0.f;
-  const float g1 = glp ? glp[row] : 0.f;
-  const float G = g1 + (gextra ? gextra[row] : 0.f);
-  const float a = -G + ge * (l - (ent ? ent[row] : 0.f));
-  const int64_t lab = labels ? labels[row] : -1;
+  const int row = blockIdx.x, V = b.V;
+  const e* x = reinterpret_cast<const e*>(b.logits) + (int64_t)row * b.stride;
+  e* o = reinterpret_cast<e*>(b.out) + (int64_t)row * b.out_stride;
+  const float inv_temp = b.inv_temp;
+  const float l = b.lse[row];
+  const float ge = b.gent ? b.gent[row] : 0.f;
+  const float g1 = b.glp ? b.glp[row] : 0.f;
+  const int e0 = b.extra_ptr ? b.extra_ptr[row] : 0, e1 = b.extra_ptr ? b.extra_ptr[row + 1] : 0;
+  float G = g1;
+  for (int f = e0; f < e1; ++f) G += b.gextra[f];                    // a handful per fork row, none elsewhere (uniform loop)
+  const float a = -G + ge * (l - (b.ent ? b.ent[row] : 0.f));
+  const int64_t lab = b.labels ? b.labels[row] : -1;
   const float k = LOG2E * inv_temp, l2 = l * LOG2E;
   const int nv = V >> 3;
   for (int i = threadIdx.x; i < nv; i += 256) {
@@ -113,59 +134,70 @@ __global__ __launch_bounds__(256) void logprob_entropy_bwd_kernel(void* __restri
       if (8 * i + j == lab) g += g1;
       v[j] = (e)(g * inv_temp);
     }
-    *reinterpret_cast<v8*>(x + 8 * i) = v;
+    *reinterpret_cast<v8*>(o + 8 * i) = v;
   }
   for (int i = (nv << 3) + threadIdx.x; i < V; i += 256) {
     const float xs = (float)x[i] * inv_temp;
     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf((float)x[i], k, -l2));
     float g = p * (a - ge * xs);
     if (i == lab) g += g1;
-    x[i] = (e)(g * inv_temp);
+    o[i] = (e)(g * inv_temp);
   }
+  if (e1 > e0) {                                                      // one-hot terms of the extra picks (distinct tokens: children of one node)
+    __syncthreads();
+    for (int f = e0 + threadIdx.x; f < e1; f += 256) {
+      const int64_t le = b.extra_labels[f];
+      if (le >= 0 && le < V) o[le] = (e)((float)o[le] + b.gextra[f] * inv_temp);
+    }
+  }
+}
+
+int fwd_launch(FwdArgs a, int32_t dtype, float temperature, void* stream) {
+  if (!a.logits || a.R <= 0 || a.V <= 0 || (a.lp && !a.labels) || !(temperature > 0.f)) return DTA_EINVAL;
+  if (a.extra_ptr && (!a.extra_labels || !a.extra_lp)) return DTA_EINVAL;
+  if (dtype != DTA_BF16 && dtype != DTA_F16 && dtype != DTA_F32) return DTA_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(a.logits) & (dtype == DTA_F32 ? 31 : 15)) || (a.stride % 8)) return DTA_EALIGN;   // 8-element vector loads
+  a.inv_temp = 1.f / temperature;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DTA_REFUSE_IF_PRIOR_ERROR();
+  if (dtype == DTA_BF16) hipLaunchKernelGGL(logprob_entropy_fwd_kernel<DTA_BF16>, dim3(a.R), dim3(256), 0, st, a);
+  else if (dtype == DTA_F16) hipLaunchKernelGGL(logprob_entropy_fwd_kernel<DTA_F16>, dim3(a.R), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(logprob_entropy_fwd_kernel<DTA_F32>, dim3(a.R), dim3(256), 0, st, a);
+  return DTA_LAUNCH_STATUS();
 }
 
 }  // namespace
 
-static int logprob_fwd_launch(const void* logits, const int64_t* labels, float* lse, float* entropy, float* logprob, float* stats,
-                              int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream);
-
-extern "C" int dta_logprob_entropy_fwd(const void* logits, const int64_t* labels, float* lse, float* entropy, float* logprob,
+extern "C" int dta_logprob_entropy_fwd(const void* logits, const int64_t* labels, const int32_t* extra_ptr, const int64_t* extra_labels,
+                                       float* lse, float* entropy, float* logprob, float* extra_logprob,
                                        int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream) {
   if (!lse) return DTA_EINVAL;
-  return logprob_fwd_launch(logits, labels, lse, entropy, logprob, nullptr, R, V, row_stride, temperature, dtype, stream);
+  FwdArgs a{logits, labels, extra_ptr, extra_labels, lse, entropy, logprob, extra_logprob, nullptr, R, V, row_stride, 1.f};
+  return fwd_launch(a, dtype, temperature, stream);
 }
 
-/* Vocab-sharded variant: stats[r] = {m, s, t, picked} of THIS shard — m = max_j y_j, s = sum 2^(y_j-m),
- * t = sum 2^(y_j-m)*y_j with y = x*log2(e)/T, picked = x[labels[r]]/T if 0 <= labels[r] < V (labels are
- * shard-local, -1 = owned elsewhere) else 0.  Ranks combine them (MAX of m, then SUM of rescaled s, t, picked):
- * the arithmetic of vocab_parallel.py:125-160 / 258-300 with one packed SUM all-reduce. */
-extern "C" int dta_logprob_entropy_shard_stats(const void* logits, const int64_t* labels, float* stats,
+extern "C" int dta_logprob_entropy_shard_stats(const void* logits, const int64_t* labels, const int32_t* extra_ptr, const int64_t* extra_labels,
+                                               float* stats, float* extra_picked,
                                                int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream) {
   if (!stats) return DTA_EINVAL;
-  return logprob_fwd_launch(logits, labels, nullptr, nullptr, nullptr, stats, R, V, row_stride, temperature, dtype, stream);
+  FwdArgs a{logits, labels, extra_ptr, extra_labels, nullptr, nullptr, nullptr, extra_picked, stats, R, V, row_stride, 1.f};
+  return fwd_launch(a, dtype, temperature, stream);
 }
 
-static int logprob_fwd_launch(const void* logits, const int64_t* labels, float* lse, float* entropy, float* logprob, float* stats,
-                              int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream) {
-  if (!logits || R <= 0 || V <= 0 || (logprob && !labels) || !(temperature > 0.f)) return DTA_EINVAL;
-  if (dtype != DTA_BF16 && dtype != DTA_F16) return DTA_EUNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(logits) & 15) || (row_stride % 8)) return DTA_EALIGN;
+extern "C" int dta_logprob_entropy_bwd(const void* logits, void* dlogits, const int64_t* labels, const int32_t* extra_ptr, const int64_t* extra_labels,
+                                       const float* lse, const float* entropy,
+                                       const float* g_logprob, const float* g_extra_logprob, const float* g_entropy,
+                                       int32_t R, int32_t V, int64_t row_stride, int64_t out_row_stride, float temperature, int32_t dtype, void* stream) {
+  if (!logits || !dlogits || !lse || R <= 0 || V <= 0 || (g_entropy && !entropy) || (g_logprob && !labels) || !(temperature > 0.f)) return DTA_EINVAL;
+  if (extra_ptr && (!extra_labels || !g_extra_logprob)) return DTA_EINVAL;
+  if (dtype != DTA_BF16 && dtype != DTA_F16 && dtype != DTA_F32) return DTA_EUNSUPPORTED;
+  const uintptr_t am = dtype == DTA_F32 ? 31 : 15;
+  if ((reinterpret_cast<uintptr_t>(logits) & am) || (reinterpret_cast<uintptr_t>(dlogits) & am) || (row_stride % 8) || (out_row_stride % 8)) return DTA_EALIGN;
+  BwdArgs b{logits, dlogits, labels, extra_ptr, extra_labels, lse, entropy, g_logprob, g_extra_logprob, g_entropy, R, V, row_stride, out_row_stride, 1.f / temperature};
   hipStream_t st = static_cast<hipStream_t>(stream);
-  (void)hipGetLastError();
-  if (dtype == DTA_BF16) hipLaunchKernelGGL(logprob_entropy_fwd_kernel<DTA_BF16>, dim3(R), dim3(256), 0, st, logits, labels, lse, entropy, logprob, stats, R, V, row_stride, 1.f / temperature);
-  else hipLaunchKernelGGL(logprob_entropy_fwd_kernel<DTA_F16>, dim3(R), dim3(256), 0, st, logits, labels, lse, entropy, logprob, stats, R, V, row_stride, 1.f / temperature);
-  return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
-}
-
-extern "C" int dta_logprob_entropy_bwd(void* logits_inout, const int64_t* labels, const float* lse, const float* entropy,
-                                       const float* g_logprob, const float* g_extra, const float* g_entropy,
-                                       int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream) {
-  if (!logits_inout || !lse || R <= 0 || V <= 0 || (g_entropy && !entropy) || (g_logprob && !labels) || !(temperature > 0.f)) return DTA_EINVAL;
-  if (dtype != DTA_BF16 && dtype != DTA_F16) return DTA_EUNSUPPORTED;
-  if ((reinterpret_cast<uintptr_t>(logits_inout) & 15) || (row_stride % 8)) return DTA_EALIGN;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  (void)hipGetLastError();
-  if (dtype == DTA_BF16) hipLaunchKernelGGL(logprob_entropy_bwd_kernel<DTA_BF16>, dim3(R), dim3(256), 0, st, logits_inout, labels, lse, entropy, g_logprob, g_extra, g_entropy, R, V, row_stride, 1.f / temperature);
-  else hipLaunchKernelGGL(logprob_entropy_bwd_kernel<DTA_F16>, dim3(R), dim3(256), 0, st, logits_inout, labels, lse, entropy, g_logprob, g_extra, g_entropy, R, V, row_stride, 1.f / temperature);
-  return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
+  DTA_REFUSE_IF_PRIOR_ERROR();
+  if (dtype == DTA_BF16) hipLaunchKernelGGL(logprob_entropy_bwd_kernel<DTA_BF16>, dim3(R), dim3(256), 0, st, b);
+  else if (dtype == DTA_F16) hipLaunchKernelGGL(logprob_entropy_bwd_kernel<DTA_F16>, dim3(R), dim3(256), 0, st, b);
+  else hipLaunchKernelGGL(logprob_entropy_bwd_kernel<DTA_F32>, dim3(R), dim3(256), 0, st, b);
+  return DTA_LAUNCH_STATUS();
 }

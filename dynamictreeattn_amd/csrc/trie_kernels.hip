@@ -4,7 +4,7 @@
 //   dta_preorder_meta  — packed pre-order token / depth / parent / subtree_end gather
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/dta.h"
+#include "dta_common.h"
 
 namespace {
 
@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void lcp_adjacent_kernel(const int64_t* __rest
     }
     if (lane == 0 && my_first < n) atomicMin(&first_bad, my_first);
     __syncthreads();
-    if (first_bad < n) break;       // uniform: every thread reads the same LDS word after the barrier
+    const bool found = first_bad < n;   // uniform: every thread reads the same LDS word after the barrier ...
+    __syncthreads();                    // ... and nobody may publish the NEXT step's candidate before everyone has read this one
+    if (found) break;
   }
   if (tid == 0) {
     const int c = first_bad;
@@ -106,24 +108,35 @@ __global__ __launch_bounds__(256) void preorder_meta_kernel(const int64_t* __res
 
 }  // namespace
 
-extern "C" int dta_version(void) { return 100; }
+extern "C" int dta_version(void) { return 200; }
+
+extern "C" int dta_take_pending_error(char* msg, int32_t cap) {
+  const hipError_t e = hipGetLastError();            // returns AND clears the thread's pending error
+  if (msg && cap > 0) {
+    const char* s = e == hipSuccess ? "" : hipGetErrorString(e);
+    int i = 0;
+    for (; s[i] && i < cap - 1; ++i) msg[i] = s[i];
+    msg[i] = 0;
+  }
+  return (int)e;
+}
 
 extern "C" int dta_lcp_adjacent(const int64_t* tokens, const int64_t* starts, const int32_t* lens, int32_t S,
                                 int32_t* out_lcp, int32_t* out_unsorted, void* stream) {
-  if (!tokens || !starts || !lens || !out_unsorted || S < 1 || (S > 1 && !out_lcp)) return DTA_EINVAL;
-  if (S == 1) return DTA_OK;
-  (void)hipGetLastError();
+  if (S < 0 || !out_unsorted || (S > 0 && (!tokens || !starts || !lens)) || (S > 1 && !out_lcp)) return DTA_EINVAL;
+  if (S <= 1) return DTA_OK;                       // an empty batch or a single sequence has no adjacent pair
+  DTA_REFUSE_IF_PRIOR_ERROR();
   hipLaunchKernelGGL(lcp_adjacent_kernel, dim3(S - 1), dim3(256), 0, static_cast<hipStream_t>(stream), tokens, starts, lens, S, out_lcp, out_unsorted);
-  return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
+  return DTA_LAUNCH_STATUS();
 }
 
 extern "C" int dta_leafize(const int32_t* lens, const int32_t* lcp, int32_t S,
                            int32_t* out_leaf_pos, int32_t* out_leaf_lcp, int32_t* out_seq_leaf, int32_t* out_M, void* stream) {
   if (!lens || !out_leaf_pos || !out_leaf_lcp || !out_seq_leaf || !out_M || S < 1 || (S > 1 && !lcp)) return DTA_EINVAL;
   if (S > (1 << 20)) return DTA_EUNSUPPORTED;
-  (void)hipGetLastError();
+  DTA_REFUSE_IF_PRIOR_ERROR();
   hipLaunchKernelGGL(leafize_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), lens, lcp, S, out_leaf_pos, out_leaf_lcp, out_seq_leaf, out_M);
-  return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
+  return DTA_LAUNCH_STATUS();
 }
 
 extern "C" int dta_preorder_meta(const int64_t* tokens, const int64_t* leaf_tok_off,
@@ -134,8 +147,8 @@ extern "C" int dta_preorder_meta(const int64_t* tokens, const int64_t* leaf_tok_
   if (!tokens || !leaf_tok_off || !seg_off || !seg_depth0 || !parent_of_seg || !brk_ptr || !brk_depth || !brk_end ||
       !out_token || !out_depth || !out_parent || !out_subtree_end || M < 1 || T < 1) return DTA_EINVAL;
   int blocks = (T + 255) / 256; if (blocks > 2048) blocks = 2048;
-  (void)hipGetLastError();
+  DTA_REFUSE_IF_PRIOR_ERROR();
   hipLaunchKernelGGL(preorder_meta_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), tokens, leaf_tok_off, seg_off, seg_depth0,
                      parent_of_seg, brk_ptr, brk_depth, brk_end, M, T, out_token, out_depth, out_parent, out_subtree_end);
-  return hipGetLastError() == hipSuccess ? DTA_OK : DTA_ELAUNCH;
+  return DTA_LAUNCH_STATUS();
 }

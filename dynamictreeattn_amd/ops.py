@@ -12,10 +12,41 @@ from . import packing
 from ._lib import check, lib, ptr
 
 _DT = {torch.bfloat16: 0, torch.float16: 1}
+_DT_LOGITS = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}      # DTA_F32: log-prob / entropy kernels only
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+class _on:
+    """Launch context of one operator call: every operand must live on ONE MI355X; the kernels go to THAT device's
+    current stream with that device made current for the call — so the reference's form
+    ``TreeTrainingEngine(cfg, 'cuda:1', ...)`` works without a prior ``torch.cuda.set_device`` (a launch on device 0
+    against device-1 pointers is a memory fault).  ``with _on(a, b) as stream: lib().dta_*(…, stream)``."""
+    __slots__ = ("dev", "_guard")
+
+    def __init__(self, *ts):
+        dev = None
+        for t in ts:
+            if t is None:
+                continue
+            if not t.is_cuda:
+                raise RuntimeError("dynamictreeattn_amd ops run on the MI355X only (tensor is on %s); there is no CPU path" % t.device)
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise RuntimeError(f"operands of one dynamictreeattn_amd op live on different devices ({dev} and {t.device})")
+        if dev is None:
+            raise RuntimeError("dynamictreeattn_amd op called without a device tensor")
+        self.dev, self._guard = dev, None
+
+    def __enter__(self):
+        if torch.cuda.current_device() != self.dev.index:
+            self._guard = torch.cuda.device(self.dev)
+            self._guard.__enter__()
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def __exit__(self, *exc):
+        if self._guard is not None:
+            self._guard.__exit__(*exc)
+        return False
 
 
 class KernelTimer:
@@ -37,9 +68,14 @@ class KernelTimer:
 
 
 def _require_cuda(*ts):
-    for t in ts:
-        if t is not None and not t.is_cuda:
-            raise RuntimeError("dynamictreeattn_amd ops run on the MI355X only (tensor is on %s); there is no CPU path" % t.device)
+    _on(*ts)
+
+
+def _launch(name: str, tensors, *args):
+    """One C-ABI call on the device / current stream of `tensors` (see _on); raises on a non-zero status."""
+    with _on(*tensors) as stream:
+        st = getattr(lib(), name)(*args, stream)
+    check(st, name)
 
 
 @dataclass
@@ -78,12 +114,13 @@ def attn_fwd_raw(q, k, v, meta: TreeAttnMeta, scale: float):
     lse = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device)          # head-major: rows of one head are contiguous
     (qs, qh), (ks, kh), (vs, vh), (os_, oh) = _strides(q), _strides(k), _strides(v), _strides(out)
     tm = KernelTimer.active
-    if tm is not None:
-        ev = tm.span("fwd"); ev[0].record()
-    st = lib().dta_tree_attn_fwd_ex(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(meta.subtree_end), ptr(meta.run_ptr), ptr(meta.runs),
-                                    Tq, Tk, meta.q_offset, Hq, Hkv, D, qs, qh, ks, kh, vs, vh, os_, oh, float(scale), _DT[q.dtype], _stream())
-    if tm is not None:
-        ev[1].record()
+    with _on(q, k, v, meta.subtree_end, meta.runs) as stream:
+        if tm is not None:
+            ev = tm.span("fwd"); ev[0].record()
+        st = lib().dta_tree_attn_fwd_ex(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(meta.subtree_end), ptr(meta.run_ptr), ptr(meta.runs),
+                                        Tq, Tk, meta.q_offset, Hq, Hkv, D, qs, qh, ks, kh, vs, vh, os_, oh, float(scale), _DT[q.dtype], stream)
+        if tm is not None:
+            ev[1].record()
     check(st, "dta_tree_attn_fwd")
     return out, lse, k, v
 
@@ -103,21 +140,22 @@ def attn_bwd_raw(q, k, v, out, dout, lse, meta: TreeAttnMeta, scale: float, dk=N
     n_splits = splits.shape[0] if splits is not None else 0
     ws = torch.empty((meta.n_slabs, Hkv, 2, packing.KTILE, D), dtype=torch.float32, device=q.device) if (units is not None and meta.n_slabs) else None
 
-    def launch(which):
+    def launch(which, stream):
         return lib().dta_tree_attn_bwd_ex(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                                           ptr(meta.subtree_end), ptr(meta.run_ptr), ptr(meta.runs), ptr(meta.ktile_qend),
                                           Tq, Tk, meta.q_offset, Hq, Hkv, D, qs, qh, ks, kh, vs, vh, os_, oh, dqs, dqh, dks, dkh,
                                           float(scale), _DT[q.dtype], 1 if accumulate else 0, which,
-                                          ptr(units), n_units, ptr(splits) if n_splits else None, n_splits, ptr(ws), _stream())
+                                          ptr(units), n_units, ptr(splits) if n_splits else None, n_splits, ptr(ws), stream)
     tm = KernelTimer.active
-    if tm is None:
-        check(launch(3), "dta_tree_attn_bwd")
-    else:
-        for which, name in ((1, "bwd_dq"), (2 | 8, "bwd_dkv"), (4, "bwd_dkv_finalize")):
-            if which == 4 and not n_splits:
-                continue
-            a, b = tm.span(name); a.record(); st = launch(which); b.record()
-            check(st, "dta_tree_attn_bwd")
+    with _on(q, k, v, out, dout, lse, dk, dv, meta.subtree_end, units) as stream:
+        if tm is None:
+            check(launch(3, stream), "dta_tree_attn_bwd")
+        else:
+            for which, name in ((1, "bwd_dq"), (2 | 8, "bwd_dkv"), (4, "bwd_dkv_finalize")):
+                if which == 4 and not n_splits:
+                    continue
+                a, b = tm.span(name); a.record(); st = launch(which, stream); b.record()
+                check(st, "dta_tree_attn_bwd")
     return dq, dk, dv
 
 
@@ -199,40 +237,44 @@ def meta_from_plan(plan: packing.SegmentPlan, subtree_end: torch.Tensor, device,
 # --------------------------------------------------------------------------------------------------
 # LM head + log-prob / entropy over packed rows (HIP statistics kernels around hipBLASLt GEMMs)
 # --------------------------------------------------------------------------------------------------
-def logprob_entropy_fwd_raw(logits, labels, want_entropy=True, temperature=1.0):
-    """logits [R,V] bf16/f16 (row-contiguous) -> (lse, entropy|None, logprob) fp32 [R]."""
-    _require_cuda(logits)
+def logprob_entropy_fwd_raw(logits, labels, want_entropy=True, temperature=1.0, extra_ptr=None, extra_labels=None, extra_out=None):
+    """logits [R,V] bf16/f16/f32 (row-contiguous) -> (lse, entropy|None, logprob|None) fp32 [R].
+    `extra_ptr` int32 [R+1] / `extra_labels` int64 [F]: further labels per row (CSR, absolute indices); their
+    log-probs are written to `extra_out` fp32 [F] (rows of this call only)."""
     R, V = logits.shape
     lse = torch.empty(R, dtype=torch.float32, device=logits.device)
     ent = torch.empty_like(lse) if want_entropy else None
     lp = torch.empty_like(lse) if labels is not None else None
-    check(lib().dta_logprob_entropy_fwd(ptr(logits), ptr(labels), ptr(lse), ptr(ent), ptr(lp), R, V, logits.stride(0),
-                                        float(temperature), _DT[logits.dtype], _stream()), "dta_logprob_entropy_fwd")
+    _launch("dta_logprob_entropy_fwd", (logits, labels, extra_ptr, extra_labels, extra_out),
+            ptr(logits), ptr(labels), ptr(extra_ptr), ptr(extra_labels), ptr(lse), ptr(ent), ptr(lp), ptr(extra_out),
+            R, V, logits.stride(0), float(temperature), _DT_LOGITS[logits.dtype])
     return lse, ent, lp
 
 
-def logprob_entropy_bwd_raw(logits, labels, lse, ent, g_lp, g_extra, g_ent, temperature=1.0):
-    """Overwrites `logits` with dLoss/dlogits."""
+def logprob_entropy_bwd_raw(logits, labels, lse, ent, g_lp, g_ent, temperature=1.0, extra_ptr=None, extra_labels=None, g_extra=None, out=None):
+    """dLoss/dlogits into `out` (None: IN PLACE over `logits`)."""
     R, V = logits.shape
-    check(lib().dta_logprob_entropy_bwd(ptr(logits), ptr(labels), ptr(lse), ptr(ent), ptr(g_lp), ptr(g_extra), ptr(g_ent), R, V,
-                                        logits.stride(0), float(temperature), _DT[logits.dtype], _stream()), "dta_logprob_entropy_bwd")
-    return logits
+    out = logits if out is None else out
+    _launch("dta_logprob_entropy_bwd", (logits, out, labels, extra_ptr, extra_labels, lse, g_lp, g_extra, g_ent),
+            ptr(logits), ptr(out), ptr(labels), ptr(extra_ptr), ptr(extra_labels), ptr(lse), ptr(ent), ptr(g_lp), ptr(g_extra), ptr(g_ent),
+            R, V, logits.stride(0), out.stride(0), float(temperature), _DT_LOGITS[logits.dtype])
+    return out
 
 
-def logprob_entropy_shard_stats_raw(logits, labels_local, temperature=1.0):
-    """Per-shard statistics [R,4] = {m, s, t, picked} (log2 domain) of logits [R, V/tp]; see dta.h."""
-    _require_cuda(logits)
+def logprob_entropy_shard_stats_raw(logits, labels_local, temperature=1.0, extra_ptr=None, extra_labels=None, extra_out=None):
+    """Per-shard statistics [R,4] = {m, s, t, picked} (log2 domain) of logits [R, V/tp]; see dta.h.  Extra picks -> raw x/T or 0."""
     R, V = logits.shape
     stats = torch.empty((R, 4), dtype=torch.float32, device=logits.device)
-    check(lib().dta_logprob_entropy_shard_stats(ptr(logits), ptr(labels_local), ptr(stats), R, V, logits.stride(0),
-                                                float(temperature), _DT[logits.dtype], _stream()), "dta_logprob_entropy_shard_stats")
+    _launch("dta_logprob_entropy_shard_stats", (logits, labels_local, extra_ptr, extra_labels, extra_out),
+            ptr(logits), ptr(labels_local), ptr(extra_ptr), ptr(extra_labels), ptr(stats), ptr(extra_out),
+            R, V, logits.stride(0), float(temperature), _DT_LOGITS[logits.dtype])
     return stats
 
 
 _LN2 = 0.6931471805599453
 
 
-def _combine_shard_stats(stats, extra_sum, group):
+def combine_shard_stats(stats, extra_sum, group):
     """Cross-rank combine of the per-shard statistics: ONE MAX all-reduce, then ONE packed SUM all-reduce
     (s, t, picked and `extra_sum`, the raw logits picked for fork children) — vocab_parallel.py:134,142,156 /
     264,273,291,298 issue 3-4 separate latency-bound reductions per chunk.  Returns (lse, ent, picked, extra)."""
@@ -250,46 +292,51 @@ def _combine_shard_stats(stats, extra_sum, group):
     return lse, ent, picked, extra
 
 
+def local_labels(t, vocab_offset, V):
+    """Global token ids -> ids inside the vocabulary slice [vocab_offset, vocab_offset + V); -1 = owned by another rank."""
+    return torch.where((t >= vocab_offset) & (t < vocab_offset + V), t - vocab_offset, torch.full_like(t, -1))
+
+
 class _HeadRows(torch.autograd.Function):
     """(lp_next [T], lp_fork [F], ent [T]) from hidden rows: lp_next[r] = log p(next_tok[r] | row r),
-    lp_fork[f] = log p(fork_tok[f] | row fork_rows[f]).  When the model-dtype [T, V] logits fit
+    lp_fork[f] = log p(fork_tok[f] | row of f), the forks given as a CSR over the rows (`fork_ptr` int32 [T+1]; the HIP
+    kernels pick them and add their one-hot gradient terms themselves).  When the model-dtype [T, V] logits fit
     `keep_bytes` they are produced by ONE GEMM, kept, turned into dLoss/dlogits IN PLACE in backward and
     consumed by one dgrad and one wgrad GEMM.  Otherwise rows go `chunk` at a time and the logits of a
     chunk are recomputed in backward (at most one [chunk, V] block alive).
     With `tp_group`, W is this rank's contiguous vocabulary slice starting at `vocab_offset` (labels stay global,
     vocab_parallel.py:128-130): per-shard statistics from the HIP kernel are combined with two all-reduces per
-    chunk and the hidden-state gradient is summed across the group."""
+    chunk and the hidden-state gradient is summed across the group while the weight-gradient GEMM runs."""
 
     @staticmethod
-    def forward(ctx, h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes, tp_group, vocab_offset):
+    def forward(ctx, h, W, next_tok, fork_ptr, fork_tok, fork_rows, fork_bounds, want_entropy, chunk, keep_bytes, tp_group, vocab_offset):
         T = h.shape[0]
         dev = h.device
         V = W.shape[0]
+        F_ = fork_tok.numel()
         keep = T * V * h.element_size() <= keep_bytes
         step = T if keep else chunk
         lse = torch.empty(T, dtype=torch.float32, device=dev)
         ent = torch.empty(T, dtype=torch.float32, device=dev) if (want_entropy or tp_group is not None) else None
         lp_next = torch.empty(T, dtype=torch.float32, device=dev)
-        lp_fork = torch.empty(fork_rows.numel(), dtype=torch.float32, device=dev)
+        lp_fork = torch.empty(F_, dtype=torch.float32, device=dev)
         if tp_group is not None:       # shard-local label ids; -1 = owned by another rank
-            own = lambda t: torch.where((t >= vocab_offset) & (t < vocab_offset + V), t - vocab_offset, torch.full_like(t, -1))
-            next_loc, fork_loc = own(next_tok), own(fork_tok)
+            next_loc, fork_loc = local_labels(next_tok, vocab_offset, V), local_labels(fork_tok, vocab_offset, V)
         else:
             next_loc, fork_loc = next_tok, fork_tok
+        xp = fork_ptr if F_ else None
         kept = None
         for ci, a in enumerate(range(0, T, step)):
             b = min(a + step, T)
             logits = torch.mm(h[a:b], W.t())
-            f0, f1 = (0, fork_rows.numel()) if keep else (fork_bounds[ci], fork_bounds[ci + 1])
             if tp_group is None:
-                l, e, p = logprob_entropy_fwd_raw(logits, next_loc[a:b], want_entropy)
-                if f1 > f0:
-                    lp_fork[f0:f1] = logits[fork_rows[f0:f1] - a, fork_tok[f0:f1]].float() - l[fork_rows[f0:f1] - a]
+                l, e, p = logprob_entropy_fwd_raw(logits, next_loc[a:b], want_entropy, 1.0,
+                                                  xp[a:b + 1] if F_ else None, fork_loc if F_ else None, lp_fork if F_ else None)
             else:
-                stats = logprob_entropy_shard_stats_raw(logits, next_loc[a:b])
-                fl = fork_loc[f0:f1]
-                raw = torch.where(fl >= 0, logits[fork_rows[f0:f1] - a, fl.clamp(min=0)].float(), torch.zeros(f1 - f0, device=dev))
-                l, e, picked, raw = _combine_shard_stats(stats, raw, tp_group)
+                f0, f1 = (0, F_) if keep else (fork_bounds[ci], fork_bounds[ci + 1])
+                stats = logprob_entropy_shard_stats_raw(logits, next_loc[a:b], 1.0, xp[a:b + 1] if F_ else None, fork_loc if F_ else None,
+                                                        lp_fork if F_ else None)
+                l, e, picked, raw = combine_shard_stats(stats, lp_fork[f0:f1], tp_group)
                 p = picked - l
                 if f1 > f0:
                     lp_fork[f0:f1] = raw - l[fork_rows[f0:f1] - a]
@@ -298,56 +345,124 @@ class _HeadRows(torch.autograd.Function):
                 ent[a:b] = e
             if keep:
                 kept = logits
-        ctx.save_for_backward(h, W, next_loc, fork_rows, fork_loc, lse, ent if ent is not None else lse)
-        ctx.kept, ctx.chunk, ctx.fork_bounds, ctx.want_entropy, ctx.tp_group = kept, chunk, fork_bounds, want_entropy, tp_group
+        ctx.save_for_backward(h, W, next_loc, fork_loc, lse, ent if ent is not None else lse, xp if F_ else lse)
+        ctx.kept, ctx.chunk, ctx.want_entropy, ctx.tp_group, ctx.has_forks = kept, chunk, want_entropy, tp_group, bool(F_)
         return lp_next, lp_fork, (ent if want_entropy else lse.new_zeros(0))
 
     @staticmethod
     def backward(ctx, g_next, g_fork, g_ent):
-        h, W, next_loc, fork_rows, fork_loc, lse, ent = ctx.saved_tensors
+        h, W, next_loc, fork_loc, lse, ent, xp = ctx.saved_tensors
         T = h.shape[0]
-        fb = ctx.fork_bounds
         g_next = g_next.contiguous().float()
         g_ent = g_ent.contiguous().float() if ctx.want_entropy else None
-        g_fork = g_fork.contiguous().float()
-        g_extra = None
-        if fork_rows.numel():
-            g_extra = torch.zeros(T, dtype=torch.float32, device=h.device).index_add_(0, fork_rows, g_fork)
+        g_fork = g_fork.contiguous().float() if ctx.has_forks else None
         kept = ctx.kept
         step = T if kept is not None else ctx.chunk
         dh = torch.empty_like(h)
         dW = None if kept is not None else torch.zeros(W.shape, dtype=torch.float32, device=W.device)
-        for ci, a in enumerate(range(0, T, step)):
+        pending = []
+        for a in range(0, T, step):
             b = min(a + step, T)
             logits = kept if kept is not None else torch.mm(h[a:b], W.t())
             logprob_entropy_bwd_raw(logits, next_loc[a:b], lse[a:b], ent[a:b] if ctx.want_entropy else None, g_next[a:b],
-                                    g_extra[a:b] if g_extra is not None else None, g_ent[a:b] if ctx.want_entropy else None)
-            f0, f1 = (0, fork_rows.numel()) if kept is not None else (fb[ci], fb[ci + 1])
-            if f1 > f0:
-                fl = fork_loc[f0:f1]
-                mine = fl >= 0                                   # one-hot terms only on the rank that owns the token
-                logits.index_put_((fork_rows[f0:f1][mine] - a, fl[mine]), g_fork[f0:f1][mine].to(logits.dtype), accumulate=True)
+                                    g_ent[a:b] if ctx.want_entropy else None, 1.0,
+                                    xp[a:b + 1] if ctx.has_forks else None, fork_loc if ctx.has_forks else None, g_fork)
             torch.mm(logits, W, out=dh[a:b])
+            if ctx.tp_group is not None:       # each rank saw only its vocabulary slice: sum dh while the wgrad GEMM runs
+                import torch.distributed as dist
+                pending.append(dist.all_reduce(dh[a:b], op=dist.ReduceOp.SUM, group=ctx.tp_group, async_op=True))
             if kept is not None:
                 dW = torch.mm(logits.t(), h)                 # one wgrad GEMM over all T rows (fp32 accumulate inside)
             else:
                 dW += torch.mm(logits.t(), h[a:b])
         ctx.kept = None
-        if ctx.tp_group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(dh, op=dist.ReduceOp.SUM, group=ctx.tp_group)      # each rank saw only its vocabulary slice
-        return dh, dW.to(W.dtype), None, None, None, None, None, None, None, None, None
+        for w in pending:
+            w.wait()
+        return dh, dW.to(W.dtype), None, None, None, None, None, None, None, None, None, None
 
 
-def lm_head_rows(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes=None, tp_group=None, vocab_offset=0):
-    """See _HeadRows.  `fork_bounds[c] .. fork_bounds[c+1]` = the forks whose row lies in chunk c (host list)."""
+def lm_head_rows(h, W, next_tok, fork_ptr, fork_tok, fork_rows, fork_bounds, want_entropy, chunk, keep_bytes=None, tp_group=None, vocab_offset=0):
+    """See _HeadRows.  `fork_ptr` int32 [T+1]: CSR of the forks over the rows; `fork_rows` int64 [F] their rows (ascending);
+    `fork_bounds[c] .. fork_bounds[c+1]` = the forks whose row lies in chunk c (host list; used by the vocabulary-split path)."""
     _require_cuda(h, W)
     if keep_bytes is None:
         free, _ = torch.cuda.mem_get_info(h.device)
         keep_bytes = free // 4
-    lp_next, lp_fork, ent = _HeadRows.apply(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes,
+    lp_next, lp_fork, ent = _HeadRows.apply(h, W, next_tok, fork_ptr, fork_tok, fork_rows, fork_bounds, want_entropy, chunk, keep_bytes,
                                             tp_group, vocab_offset)
     return lp_next, lp_fork, (ent if want_entropy else None)
+
+
+class _LogProbEntropyHIP(torch.autograd.Function):
+    """The public ``gather_logprobs(_entropy)`` of vocab_parallel.py:399-467 on the HIP kernels: logits [R, V] in bf16 / f16 /
+    f32 (the reference up-casts with ``.float()``; the kernels read the stored dtype and do all arithmetic in fp32, which
+    is the same thing), labels int64 [R] with -1 = no label.  Backward writes dLoss/dlogits out of place (the caller's
+    logits stay intact) in the logits' dtype, as autograd through ``.float()`` does."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, temperature, want_entropy):
+        lse, ent, lp = logprob_entropy_fwd_raw(logits, labels, want_entropy, temperature)
+        ctx.save_for_backward(logits, labels, lse, ent if ent is not None else lse)
+        ctx.temperature, ctx.want_entropy = temperature, want_entropy
+        return lp, (ent if want_entropy else lse.new_zeros(0))
+
+    @staticmethod
+    def backward(ctx, g_lp, g_ent):
+        logits, labels, lse, ent = ctx.saved_tensors
+        out = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device)
+        logprob_entropy_bwd_raw(logits, labels, lse, ent if ctx.want_entropy else None, g_lp.contiguous().float(),
+                                g_ent.contiguous().float() if ctx.want_entropy else None, ctx.temperature, out=out)
+        return out, None, None, None
+
+
+class _ShardedLogProbEntropyHIP(torch.autograd.Function):
+    """Vocabulary-sharded form (vocab_parallel.py:82-370) on the HIP kernels: per-shard statistics, ONE MAX + ONE packed SUM
+    all-reduce for all rows (the reference issues 3-4 per 1024-row chunk), backward on the shard with shard-local labels."""
+
+    @staticmethod
+    def forward(ctx, logits, labels_local, temperature, want_entropy, group):
+        stats = logprob_entropy_shard_stats_raw(logits, labels_local, temperature)
+        lse, ent, picked, _ = combine_shard_stats(stats, stats.new_zeros(0), group)
+        ctx.save_for_backward(logits, labels_local, lse, ent)
+        ctx.temperature, ctx.want_entropy = temperature, want_entropy
+        return picked - lse, (ent if want_entropy else lse.new_zeros(0))
+
+    @staticmethod
+    def backward(ctx, g_lp, g_ent):
+        logits, labels_local, lse, ent = ctx.saved_tensors
+        out = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device)
+        logprob_entropy_bwd_raw(logits, labels_local, lse, ent if ctx.want_entropy else None, g_lp.contiguous().float(),
+                                g_ent.contiguous().float() if ctx.want_entropy else None, ctx.temperature, out=out)
+        return out, None, None, None, None
+
+
+def _rows_for_kernel(logits2d):
+    """Row-contiguous [R, V] view whose row stride is a multiple of 8 elements (16-byte vector loads); copies only when needed."""
+    if logits2d.stride(-1) != 1:
+        logits2d = logits2d.contiguous()
+    if logits2d.stride(0) % 8 or logits2d.data_ptr() % 32:
+        R, V = logits2d.shape
+        buf = torch.empty((R, (V + 7) // 8 * 8), dtype=logits2d.dtype, device=logits2d.device)
+        view = buf[:, :V]
+        view.copy_(logits2d)
+        return view
+    return logits2d
+
+
+def logprob_entropy(logits2d, labels1d, temperature=1.0, want_entropy=True, tp_group=None):
+    """(logprob [R], entropy [R] | None) of CUDA logits [R, V] through the HIP kernels; labels1d int64 [R], -1 = none.
+    With `tp_group`, logits hold this rank's vocabulary slice (rank * V .. ) and labels are global ids."""
+    if logits2d.dtype not in _DT_LOGITS:
+        raise TypeError("logprob_entropy supports bf16 / f16 / f32 logits (got %s)" % logits2d.dtype)
+    x = _rows_for_kernel(logits2d)
+    if tp_group is None:
+        lp, ent = _LogProbEntropyHIP.apply(x, labels1d, float(temperature), want_entropy)
+    else:
+        import torch.distributed as dist
+        V = x.shape[1]
+        lab = local_labels(labels1d, dist.get_rank(tp_group) * V, V)
+        lp, ent = _ShardedLogProbEntropyHIP.apply(x, lab, float(temperature), want_entropy, tp_group)
+    return lp, (ent if want_entropy else None)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -368,7 +483,7 @@ class _RMSNorm(torch.autograd.Function):
             xo = torch.empty_like(x2)
         else:
             d2, xo = None, None
-        check(lib().dta_rmsnorm_fwd(ptr(x2), ptr(d2), ptr(w), ptr(xo), ptr(y), ptr(rstd), R, H, float(eps), _DT[x.dtype], _stream()), "dta_rmsnorm_fwd")
+        _launch("dta_rmsnorm_fwd", (x2, d2, w), ptr(x2), ptr(d2), ptr(w), ptr(xo), ptr(y), ptr(rstd), R, H, float(eps), _DT[x.dtype])
         xin = xo if xo is not None else x2
         ctx.save_for_backward(xin, w, rstd)
         ctx.has_delta = delta is not None
@@ -382,7 +497,7 @@ class _RMSNorm(torch.autograd.Function):
         gr = g_res.contiguous().view(R, H) if g_res is not None else None
         dx = torch.empty_like(x2)
         part = torch.empty(lib().dta_rmsnorm_bwd_blocks(R), H, dtype=torch.float32, device=x2.device)
-        check(lib().dta_rmsnorm_bwd(ptr(x2), ptr(w), ptr(dy2), ptr(gr), ptr(rstd), ptr(dx), ptr(part), R, H, _DT[x2.dtype], _stream()), "dta_rmsnorm_bwd")
+        _launch("dta_rmsnorm_bwd", (x2, w, dy2, gr), ptr(x2), ptr(w), ptr(dy2), ptr(gr), ptr(rstd), ptr(dx), ptr(part), R, H, _DT[x2.dtype])
         dx = dx.view(dy.shape)
         return dx, (dx if ctx.has_delta else None), part.sum(0).to(w.dtype), None
 
@@ -405,8 +520,8 @@ class _QKNormRope(torch.autograd.Function):
             x = x.contiguous()
         y = torch.empty((T, NH, D), dtype=x.dtype, device=x.device)
         rstd = torch.empty(T * NH, dtype=torch.float32, device=x.device) if w is not None else None
-        check(lib().dta_qk_norm_rope_fwd(ptr(x), ptr(w), ptr(cos_sin), ptr(y), ptr(rstd), T, NH, D, x.stride(0), float(eps),
-                                         _DT[x.dtype], _stream()), "dta_qk_norm_rope_fwd")
+        _launch("dta_qk_norm_rope_fwd", (x, w, cos_sin), ptr(x), ptr(w), ptr(cos_sin), ptr(y), ptr(rstd), T, NH, D, x.stride(0), float(eps),
+                _DT[x.dtype])
         ctx.save_for_backward(x, w if w is not None else cos_sin, cos_sin, rstd if rstd is not None else cos_sin)
         ctx.has_w = w is not None
         return y
@@ -421,9 +536,8 @@ class _QKNormRope(torch.autograd.Function):
         part = None
         if ctx.has_w:
             part = torch.empty(lib().dta_qk_norm_rope_bwd_blocks(T * NH), D, dtype=torch.float32, device=x.device)
-        check(lib().dta_qk_norm_rope_bwd(ptr(x), ptr(w) if ctx.has_w else None, ptr(cos_sin), ptr(dy), ptr(rstd) if ctx.has_w else None,
-                                         ptr(dx), ptr(part), T, NH, D, x.stride(0), dy.stride(0), dy.stride(1), dx.stride(0), _DT[x.dtype], _stream()),
-              "dta_qk_norm_rope_bwd")
+        _launch("dta_qk_norm_rope_bwd", (x, cos_sin, dy), ptr(x), ptr(w) if ctx.has_w else None, ptr(cos_sin), ptr(dy), ptr(rstd) if ctx.has_w else None,
+                ptr(dx), ptr(part), T, NH, D, x.stride(0), dy.stride(0), dy.stride(1), dx.stride(0), _DT[x.dtype])
         return dx, (part.sum(0).to(w.dtype) if ctx.has_w else None), None, None
 
 
@@ -442,8 +556,8 @@ class _QKVPrep(torch.autograd.Function):
         for x, w, NH in ((qkv[:, :Hq], wq, Hq), (qkv[:, Hq:Hq + Hkv], wk, Hkv)):
             y = torch.empty((T, NH, D), dtype=qkv.dtype, device=qkv.device)
             rstd = torch.empty(T * NH, dtype=torch.float32, device=qkv.device) if w is not None else None
-            check(lib().dta_qk_norm_rope_fwd(ptr(x), ptr(w), ptr(cos_sin), ptr(y), ptr(rstd), T, NH, D, qkv.stride(0), float(eps),
-                                             _DT[qkv.dtype], _stream()), "dta_qk_norm_rope_fwd")
+            _launch("dta_qk_norm_rope_fwd", (qkv, w, cos_sin), ptr(x), ptr(w), ptr(cos_sin), ptr(y), ptr(rstd), T, NH, D, qkv.stride(0), float(eps),
+                    _DT[qkv.dtype])
             outs.append(y); rstds.append(rstd if rstd is not None else cos_sin)
         ctx.save_for_backward(qkv, wq if wq is not None else cos_sin, wk if wk is not None else cos_sin, cos_sin, rstds[0], rstds[1])
         ctx.has_w = (wq is not None, wk is not None)
@@ -461,9 +575,9 @@ class _QKVPrep(torch.autograd.Function):
             if dy.stride(2) != 1:
                 dy = dy.contiguous()
             part = torch.empty(lib().dta_qk_norm_rope_bwd_blocks(T * NH), D, dtype=torch.float32, device=qkv.device) if has_w else None
-            check(lib().dta_qk_norm_rope_bwd(ptr(qkv[:, lo:lo + NH]), ptr(w) if has_w else None, ptr(cos_sin), ptr(dy), ptr(rstd) if has_w else None,
-                                             ptr(d[:, lo:lo + NH]), ptr(part), T, NH, D, qkv.stride(0), dy.stride(0), dy.stride(1), d.stride(0),
-                                             _DT[qkv.dtype], _stream()), "dta_qk_norm_rope_bwd")
+            _launch("dta_qk_norm_rope_bwd", (qkv, cos_sin, dy), ptr(qkv[:, lo:lo + NH]), ptr(w) if has_w else None, ptr(cos_sin), ptr(dy),
+                    ptr(rstd) if has_w else None, ptr(d[:, lo:lo + NH]), ptr(part), T, NH, D, qkv.stride(0), dy.stride(0), dy.stride(1), d.stride(0),
+                    _DT[qkv.dtype])
             dws.append(part.sum(0).to(w.dtype) if has_w else None)
         d[:, Hq + Hkv:].copy_(dv)
         return d, dws[0], dws[1], None, None, None, None
@@ -504,7 +618,7 @@ class _SwiGLU(torch.autograd.Function):
             C, ld = g.shape[1], g.shape[1]
         rows = g.shape[0]
         y = torch.empty((rows, C), dtype=g.dtype, device=g.device)
-        check(lib().dta_swiglu_fwd(ptr(g), ptr(u), ptr(y), rows, C, ld, _DT[g.dtype], _stream()), "dta_swiglu_fwd")
+        _launch("dta_swiglu_fwd", (g, u), ptr(g), ptr(u), ptr(y), rows, C, ld, _DT[g.dtype])
         ctx.save_for_backward(g, u)
         ctx.fused, ctx.ld = gu is not None, ld
         return y
@@ -519,7 +633,7 @@ class _SwiGLU(torch.autograd.Function):
             dg, du, ldg = dgu[:, :C], dgu[:, C:], 2 * C
         else:
             dg, du, ldg = torch.empty_like(g), torch.empty_like(u), C
-        check(lib().dta_swiglu_bwd(ptr(g), ptr(u), ptr(dy), ptr(dg), ptr(du), rows, C, ctx.ld, ldg, _DT[g.dtype], _stream()), "dta_swiglu_bwd")
+        _launch("dta_swiglu_bwd", (g, u, dy), ptr(g), ptr(u), ptr(dy), ptr(dg), ptr(du), rows, C, ctx.ld, ldg, _DT[g.dtype])
         return (dgu, None, None) if ctx.fused else (None, dg, du)
 
 

@@ -114,22 +114,35 @@ def pad_plan(plan: SegmentPlan, multiple: int = 256) -> SegmentPlan:
     return out
 
 
-def expand_plan_host(plan: SegmentPlan):
-    """numpy mirror of dta_preorder_meta's index arithmetic (tests and CPU-side planning checks only;
-    the engine uses the HIP kernel).  Returns (seg_of_token, depth, parent, subtree_end)."""
-    T, M = plan.T, plan.M
-    seg = np.repeat(np.arange(M, dtype=np.int32), np.diff(plan.seg_off))
-    j = np.arange(T, dtype=np.int32) - plan.seg_off[seg]
-    depth = plan.seg_depth0[seg] + j
-    parent = np.where(j > 0, np.arange(T, dtype=np.int32) - 1, plan.parent_of_seg[seg]).astype(np.int32)
-    se = np.empty(T, np.int32)
-    for i in range(M):
-        a, b = plan.brk_ptr[i], plan.brk_ptr[i + 1]
-        s, e = plan.seg_off[i], plan.seg_off[i + 1]
-        if e > s:
-            k = np.searchsorted(plan.brk_depth[a:b], depth[s:e], side="right") - 1
-            se[s:e] = plan.brk_end[a:b][k]
-    return seg, depth.astype(np.int32), parent, se
+def ktile_qend_host(plan: SegmentPlan, tile: int = KTILE) -> np.ndarray:
+    """ktile_qend[j] = max subtree_end over the keys of key tile j, from the plan's closing tables alone (host,
+    O(#breaks + #tiles)): subtree_end is piecewise constant over the packed intervals [seg_off[i] + brk_depth[b] -
+    seg_depth0[i], next break), so a tile's maximum is the maximum over the intervals that touch it.  Lets the dK/dV
+    work units be planned without reading subtree_end back from the device."""
+    T = plan.T
+    nkt = (T + tile - 1) // tile
+    out = np.zeros(nkt, np.int64)
+    if T == 0:
+        return out.astype(np.int32)
+    seg = np.repeat(np.arange(plan.M, dtype=np.int64), np.diff(plan.brk_ptr))
+    start = plan.seg_off[seg].astype(np.int64) + plan.brk_depth.astype(np.int64) - plan.seg_depth0[seg].astype(np.int64)
+    nxt = np.empty_like(start)
+    nxt[:-1] = start[1:]
+    last_of_seg = plan.brk_ptr[1:].astype(np.int64) - 1
+    nxt[last_of_seg] = plan.seg_off[1:].astype(np.int64)
+    keep = nxt > start                                  # empty segments keep a dummy break
+    start, nxt, val = start[keep], nxt[keep], plan.brk_end.astype(np.int64)[keep]
+    t0, t1 = start // tile, (nxt - 1) // tile
+    np.maximum.at(out, t0, val)
+    np.maximum.at(out, t1, val)
+    inner = t1 - t0 - 1                                 # tiles wholly inside one interval belong to it alone
+    has = inner > 0
+    if has.any():
+        cnt = inner[has]
+        first = (t0[has] + 1)
+        idx = np.repeat(first - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt) + np.arange(int(cnt.sum()))
+        out[idx] = np.maximum(out[idx], np.repeat(val[has], cnt))
+    return out.astype(np.int32)
 
 
 def plan_qtile_runs(plan: SegmentPlan, tile: int = QTILE):

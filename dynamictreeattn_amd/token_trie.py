@@ -48,25 +48,46 @@ class _DeviceTokens:
 
 def _device_trie_arrays(dev: _DeviceTokens, order: Sequence[int], leafize: bool):
     """LCP of adjacent sequences taken in `order` (and, if asked, the leafization) on the GPU.
-    Returns (lcp list, unsorted pair count, leaf positions or None)."""
+    Returns (lcp list, unsorted pair count, leaf positions or None).  ONE device->host read per call: both kernels write
+    into one int32 buffer [lcp (S-1) | unsorted | leaf_pos (S) | leaf_lcp (S) | seq_leaf (S) | M]."""
     from ._lib import check, lib, ptr
     S = len(order)
     d = dev.device
     idx = np.asarray(order, np.int64)
-    starts = torch.from_numpy(dev.starts[idx]).to(d)
-    lens = torch.from_numpy(dev.lens[idx]).to(d)
-    out = torch.zeros(max(S - 1, 1) + 1, dtype=torch.int32, device=d)        # [lcp..., unsorted]
-    stream = torch.cuda.current_stream().cuda_stream
-    check(lib().dta_lcp_adjacent(ptr(dev.tokens), ptr(starts), ptr(lens), S, ptr(out), out[-1:].data_ptr(), stream), "dta_lcp_adjacent")
+    meta = torch.from_numpy(np.concatenate([dev.starts[idx], dev.lens[idx].astype(np.int64)])).to(d)     # one H2D: starts | lens
+    starts, lens = meta[:S], meta[S:].to(torch.int32)
+    n_lcp = max(S - 1, 1)
+    buf = torch.zeros(n_lcp + 1 + (3 * S + 1 if leafize else 0), dtype=torch.int32, device=d)
+    with torch.cuda.device(d):
+        stream = torch.cuda.current_stream(d).cuda_stream
+        check(lib().dta_lcp_adjacent(ptr(dev.tokens), ptr(starts), ptr(lens), S, ptr(buf), buf[n_lcp:].data_ptr(), stream), "dta_lcp_adjacent")
+        if leafize:
+            o = n_lcp + 1
+            check(lib().dta_leafize(ptr(lens), ptr(buf), S, buf[o:].data_ptr(), buf[o + S:].data_ptr(), buf[o + 2 * S:].data_ptr(),
+                                    buf[o + 3 * S:].data_ptr(), stream), "dta_leafize")
+    host = buf.cpu().numpy()
     if not leafize:
-        host = out.cpu().numpy()
-        return host[:S - 1].tolist(), int(host[-1]), None
-    res = torch.empty(3 * S + 1, dtype=torch.int32, device=d)                # leaf_pos | leaf_lcp | seq_leaf | M
-    check(lib().dta_leafize(ptr(lens), ptr(out), S, res[:S].data_ptr(), res[S:2 * S].data_ptr(), res[2 * S:3 * S].data_ptr(),
-                            res[3 * S:].data_ptr(), stream), "dta_leafize")
-    host, r = out.cpu().numpy(), res.cpu().numpy()
+        return host[:S - 1].tolist(), int(host[n_lcp]), None
+    r = host[n_lcp + 1:]
     M = int(r[3 * S])
-    return r[S:S + M - 1].tolist(), int(host[-1]), r[:M].tolist()
+    return r[S:S + M - 1].tolist(), int(host[n_lcp]), r[:M].tolist()
+
+
+def _range_min_table(a: Sequence[int]):
+    """Sparse table for range-minimum queries over `a` (host; M leaves)."""
+    t = [np.asarray(a, np.int64)]
+    k = 1
+    while 2 * k <= len(a):
+        prev = t[-1]
+        t.append(np.minimum(prev[:-k], prev[k:]))
+        k *= 2
+    return t
+
+
+def _range_min(t, lo: int, hi: int) -> int:
+    """min(a[lo:hi]), hi > lo."""
+    j = (hi - lo).bit_length() - 1
+    return int(min(t[j][lo], t[j][hi - (1 << j)]))
 
 
 class TokenTrie:
@@ -78,16 +99,25 @@ class TokenTrie:
         for sid, att in enumerate(attachs):                 # mutates the caller's dicts, as the reference does
             att["_sequence_batch_id"] = sid
         S = len(inputs)
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("TokenTrie needs the MI355X: LCP / leafization run in HIP kernels and there is no CPU path")
+            device = torch.device("cuda", torch.cuda.current_device())
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if S == 0:                                          # an empty batch is an empty trie (token_trie.py:52-82 with no inputs)
+            self._dev = _DeviceTokens([], device)
+            self.inputs, self.attach_lists, self._leaf_src, self.lcp_lens, self.lens = [], [], [], [], []
+            self._sorted_pos, self._sorted_lcp = [], []
+            self.n_sequences, self.n_tokens = 0, 0
+            return
         if sorted:
             order = list(range(S))
         else:
             keys = _sort_keys(inputs)
             order = list(range(S))
             order.sort(key=keys.__getitem__)
-        if device is None:
-            if not torch.cuda.is_available():
-                raise RuntimeError("TokenTrie needs the MI355X: LCP / leafization run in HIP kernels and there is no CPU path")
-            device = torch.device("cuda", torch.cuda.current_device())
         self._dev = _DeviceTokens(inputs, device)
         leaf_lcp, unsorted, leaf_pos = _device_trie_arrays(self._dev, order, True)
         if unsorted:
@@ -101,6 +131,9 @@ class TokenTrie:
             first = pos + 1
         self.lcp_lens = [int(c) for c in leaf_lcp]
         self.lens = [int(self._dev.lens[s]) for s in self._leaf_src]
+        # the leaves are in lexicographic order here: remember it, so that the LCP of ANY two leaves later is a range minimum
+        self._sorted_pos = list(range(len(self.lens)))      # current leaf -> position in the sorted leaf order
+        self._sorted_lcp = list(self.lcp_lens)              # LCP of sorted neighbours
         self.n_sequences = S
         self.n_tokens = int(self._dev.lens.sum())
 
@@ -115,8 +148,25 @@ class TokenTrie:
         self.attach_lists = [self.attach_lists[i] for i in order]
         self.lens = [self.lens[i] for i in order]
         self._leaf_src = [self._leaf_src[i] for i in order]
-        # LCPs are recomputed from the tokens (token_trie.py:94) — on the device-resident copy
-        self.lcp_lens, _, _ = _device_trie_arrays(self._dev, self._leaf_src, False) if len(order) > 1 else ([], 0, None)
+        self._sorted_pos = [self._sorted_pos[i] for i in order]
+        # The reference recomputes the adjacent LCPs from the tokens (token_trie.py:94).  For leaves of ONE sorted batch the
+        # LCP of two leaves is the minimum of the sorted-neighbour LCPs between them, so the new values follow on the host
+        # from the construction-time kernel output: no launch and no device->host read per permutation.
+        # `lcp_from_tokens()` is the kernel form of the same values (tests compare the two).
+        if len(order) > 1:
+            t = _range_min_table(self._sorted_lcp)
+            sp = self._sorted_pos
+            self.lcp_lens = [_range_min(t, min(sp[i], sp[i + 1]), max(sp[i], sp[i + 1])) if sp[i] != sp[i + 1] else int(self.lens[i])
+                             for i in range(len(order) - 1)]
+        else:
+            self.lcp_lens = []
+
+    def lcp_from_tokens(self) -> List[int]:
+        """Adjacent LCPs of the leaves in their CURRENT order, recomputed from the device-resident tokens by
+        `dta_lcp_adjacent` (what token_trie.py:94 does with `_lcp_torch`)."""
+        if len(self._leaf_src) < 2:
+            return []
+        return _device_trie_arrays(self._dev, self._leaf_src, False)[0]
 
     def forward_permute(self):
         self.permute(CompressedTrie(self.lens, self.lcp_lens).get_order_forward()[0])

@@ -69,6 +69,8 @@ def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tenso
     fc_dev = torch.from_numpy(fork_child).to(dev)
     fp_dev = torch.from_numpy(fork_parent).to(dev)
     ftok = tokens[fc_dev] if fork_child.size else tokens.new_zeros(0)
+    # CSR of the forks over the rows (the HIP kernels pick the fork tokens' log-probs and add their one-hot gradient terms)
+    fork_ptr = torch.searchsorted(fp_dev, torch.arange(T + 1, device=dev)).to(torch.int32) if fork_child.size else None
     nxt = torch.cat([tokens[1:], tokens.new_zeros(1)])
     bounds = np.searchsorted(fork_parent, np.arange(0, T + chunk, chunk)).tolist()
     if tp_group is not None:
@@ -78,10 +80,10 @@ def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tenso
         tp, rk = dist.get_world_size(tp_group), dist.get_rank(tp_group)
         Vp = W.shape[0] // tp
         assert Vp * tp == W.shape[0], "vocabulary must divide by the tensor-parallel size"
-        lp_next, lp_fork, ent = ops.lm_head_rows(h, W[rk * Vp:(rk + 1) * Vp], nxt, fp_dev, ftok, bounds, want_entropy, chunk,
+        lp_next, lp_fork, ent = ops.lm_head_rows(h, W[rk * Vp:(rk + 1) * Vp], nxt, fork_ptr, ftok, fp_dev, bounds, want_entropy, chunk,
                                                  tp_group=tp_group, vocab_offset=rk * Vp)
     else:
-        lp_next, lp_fork, ent = ops.lm_head_rows(h, W, nxt, fp_dev, ftok, bounds, want_entropy, chunk)
+        lp_next, lp_fork, ent = ops.lm_head_rows(h, W, nxt, fork_ptr, ftok, fp_dev, bounds, want_entropy, chunk)
     chain = torch.zeros(T, dtype=torch.bool, device=dev)           # lp_next[r] = log p(tokens[r+1] | node r)
     chain[1:] = parent[1:] == torch.arange(0, T - 1, device=dev, dtype=parent.dtype)
     lp = torch.cat([lp_next.new_zeros(1), lp_next[:-1]]) * chain
@@ -99,6 +101,12 @@ class _PackedTrie:
     PAD_TO = 256
 
     def __init__(self, trie, device, n_kv_heads: int = 8):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if trie._dev.device != device:
+            raise RuntimeError(f"TokenTrie holds its tokens on {trie._dev.device} but the engine runs on {device}: build it with "
+                               f"TokenTrie(..., device={str(device)!r}) (or torch.cuda.set_device) so that one GPU owns the whole pass")
         plan = packing.plan_segments(trie.lens, trie.lcp_lens)
         self.n_real_tokens = plan.T
         M_real = plan.M
@@ -125,9 +133,14 @@ class _PackedTrie:
         meta_i = torch.empty(3, T, dtype=torch.int32, device=device)
         self.depth, self.parent, self.subtree_end = meta_i[0], meta_i[1], meta_i[2]
         self._expand(trie._dev.tokens, leaf_off_d, seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, M, T)
-        self.meta = ops.TreeAttnMeta(T=T, subtree_end=self.subtree_end, run_ptr=run_ptr_d, runs=runs_d.view(-1, 4),
-                                     ktile_qend=ops.ktile_qend_from(self.subtree_end))
-        ops.attach_dkv_units(self.meta, n_kv_heads)
+        # key-tile query ends and the balanced dK/dV work units come from the host plan: no device->host read
+        kq = packing.ktile_qend_host(plan)
+        units, splits, n_slabs = packing.plan_dkv_units(kq, T, T, 0, n_kv_heads)
+        tail = torch.from_numpy(np.concatenate([kq, units.reshape(-1), splits.reshape(-1)]).astype(np.int32, copy=False)).to(device, non_blocking=True)
+        nk, nu = kq.size, units.size
+        self.meta = ops.TreeAttnMeta(T=T, subtree_end=self.subtree_end, run_ptr=run_ptr_d, runs=runs_d.view(-1, 4), ktile_qend=tail[:nk],
+                                     dkv_units=tail[nk:nk + nu].view(-1, 4), dkv_splits=tail[nk + nu:].view(-1, 4) if splits.shape[0] else None,
+                                     n_slabs=n_slabs)
         first = plan.seg_off[:-1].astype(np.int64)
         nonempty = np.diff(plan.seg_off) > 0
         par = plan.parent_of_seg.astype(np.int64)
@@ -139,21 +152,30 @@ class _PackedTrie:
             pieces = [np.arange(b, e, dtype=np.int64) for b, e in plan.path_runs[i]]
             pieces.append(np.arange(plan.seg_off[i], plan.seg_off[i + 1], dtype=np.int64))
             paths.append(np.concatenate(pieces))
-        cat = torch.from_numpy(np.concatenate(paths)).to(device, non_blocking=True)
-        self.paths = list(torch.split(cat, [p.size for p in paths]))
+        self.path_cat = torch.from_numpy(np.concatenate(paths) if paths else np.zeros(0, np.int64)).to(device, non_blocking=True)
+        self.path_sizes = [p.size for p in paths]
+        self.paths = list(torch.split(self.path_cat, self.path_sizes))
 
     def _expand(self, tokens, leaf_off, seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, M, T):
         from ._lib import check, lib, ptr
-        st = lib().dta_preorder_meta(ptr(tokens), ptr(leaf_off), ptr(seg_off), ptr(seg_d0), ptr(par_seg), ptr(brk_ptr), ptr(brk_depth),
-                                     ptr(brk_end), M, T, ptr(self.tokens), ptr(self.depth), ptr(self.parent), ptr(self.subtree_end),
-                                     torch.cuda.current_stream().cuda_stream)
+        with ops._on(tokens, leaf_off, seg_off, self.tokens) as stream:
+            st = lib().dta_preorder_meta(ptr(tokens), ptr(leaf_off), ptr(seg_off), ptr(seg_d0), ptr(par_seg), ptr(brk_ptr), ptr(brk_depth),
+                                         ptr(brk_end), M, T, ptr(self.tokens), ptr(self.depth), ptr(self.parent), ptr(self.subtree_end), stream)
         check(st, "dta_preorder_meta")
 
 
 class TreeTrainingEngine:
     def __init__(self, model_config, device, dtype: torch.dtype, max_seq_len: int, forward_only: bool = False):
+        if torch.device(device).type == "cuda" and dtype not in (torch.bfloat16, torch.float16):
+            # the reference also runs fp32 models (run.py:122-132, through sdpa); the MFMA tree-attention kernels here are
+            # instantiated for the 16-bit dtypes only, so refuse up front with the reason instead of failing deep inside a layer
+            raise TypeError(f"TreeTrainingEngine on the MI355X HIP path supports dtype torch.bfloat16 / torch.float16, got {dtype}: "
+                            "there is no fp32 instantiation of the tree-attention kernels (use the reference on CPU, or the "
+                            "oracle in oracle/model_oracle.py, for fp32 gradient checks)")
         self.model = None
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.dtype = dtype
         self.max_seq_len = max_seq_len
         self.forward_only = forward_only
@@ -173,6 +195,9 @@ class TreeTrainingEngine:
         longest = max(token_trie.lens) if token_trie.lens else 0
         assert longest <= self.max_seq_len, (                                   # tte:162-164, 289-291
             f"Exceeds max_seq_len: cur_len=0, new_tokens={longest}, max={self.max_seq_len}")
+        p0 = next(iter(self.model.parameters()), None) if hasattr(self.model, "parameters") else None
+        if p0 is not None and (p0.dtype != self.dtype or p0.device != self.device):
+            raise RuntimeError(f"model parameters are {p0.dtype} on {p0.device}; this engine was built for {self.dtype} on {self.device}")
         packed = _PackedTrie(token_trie, self.device, self.n_kv_heads)
         self.last_packed = packed
         return packed
@@ -199,15 +224,18 @@ class TreeTrainingEngine:
         return int(self.attn_keep_fraction * free)
 
     def _path_losses(self, packed, token_trie, lp, ent, loss_fn):
-        total = None
+        """Σ over original sequences of loss_fn(logprobs[:len-1], entropy[:len], attachment) (tte:379-398).  The root paths of
+        ALL leaves are gathered by one indexing kernel per vector; every sequence then gets VIEWS of its leaf's path (a
+        sequence folded onto a leaf is a prefix of it), and the user's callback runs per sequence as in the reference."""
+        lp_all, ent_all = lp[packed.path_cat], ent[packed.path_cat]
+        terms, o = [], 0
         for i, attach_list in enumerate(token_trie.attach_lists):
-            idx = packed.paths[i]
-            lp_path = lp[idx[1:]]
-            ent_path = ent[idx]
-            for attachment, length in attach_list:                              # tte:379-398
-                term = loss_fn(lp_path[:length - 1], ent_path[:length], attachment)
-                total = term if total is None else total + term
-        return total
+            for attachment, length in attach_list:
+                terms.append(loss_fn(lp_all[o + 1:o + length], ent_all[o:o + length], attachment))
+            o += packed.path_sizes[i]
+        if not terms:
+            return None
+        return terms[0] if len(terms) == 1 else torch.stack([t.reshape(()) for t in terms]).sum()
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -216,6 +244,8 @@ class TreeTrainingEngine:
         self.model = model
         self.returns = [None] * token_trie.n_sequences
         self.forkpos_list = _get_forkpos(None, token_trie.lcp_lens, None)
+        if token_trie.n_sequences == 0:
+            return self.returns
         packed = self._pack(token_trie)
         h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, False)
         lp, _ = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, False, self.head_chunk,
@@ -233,6 +263,8 @@ class TreeTrainingEngine:
         self.model = model
         lens = [int(ids.size(0)) for ids in token_trie.inputs]
         self.forkpos_list = _get_forkpos(lens, token_trie.lcp_lens, block_size)
+        if token_trie.n_sequences == 0:          # an empty bin of a data-parallel step: no loss, no gradient (the caller still reduces)
+            return 0.0
         packed = self._pack(token_trie)
         chunk = min(self.head_chunk, block_size) if block_size else self.head_chunk
         ckpt = self._should_checkpoint(model, packed.plan.T)

@@ -1,13 +1,17 @@
 """Log-probabilities / entropy from logits — drop-in for the reference's ``vocab_parallel``
 (vocab_parallel.py:399-467): ``gather_logprobs`` / ``gather_logprobs_entropy`` with the same
-arguments, fp32 results, row chunking to cap memory, and an optional vocab-sharded (TP) path.
+arguments, fp32 results, and an optional vocab-sharded (TP) path.
+
+CUDA logits (bf16 / f16 / f32) go through the HIP kernels ``dta_logprob_entropy_fwd/bwd`` (or
+``dta_logprob_entropy_shard_stats`` with a ``tp_group``) behind autograd Functions (ops.logprob_entropy): one read of
+the logits per direction, no fp32 copy of them, so ``chunk_size`` has nothing left to bound there and is ignored; if the
+HIP library is missing these calls raise.  CPU logits (the reference also runs on CPU: SURVEY §6; the gloo tests) take
+the torch restatement below, which chunks rows as the reference does.
 
 Differences in mechanism, not in results:
-* rows are chunked over the flattened leading dims (the reference chunks dim 0, so for the
-  engine's ``[1,B,V]`` logits it does not chunk at all — SURVEY §8 a13);
-* the vocab-parallel branch packs its SUM reductions into ONE all-reduce per chunk after the MAX
-  all-reduce (2 latency-bound RCCL calls instead of 3-4: vocab_parallel.py:134,142,156 /
-  264,273,291,298) and saves no [rows, V/tp] tensor for backward (recomputed from the logits).
+* the vocab-parallel branch packs its SUM reductions into ONE all-reduce after the MAX all-reduce (2 latency-bound
+  RCCL calls instead of 3-4 per chunk: vocab_parallel.py:134,142,156 / 264,273,291,298) and saves no [rows, V/tp]
+  tensor for backward (recomputed from the logits);
 * the reference's shape quirk is kept: ``labels`` may hold fewer rows than ``logits`` (the engine
   passes B logits rows and B-1 labels, tte:190-193); logprobs then cover the first rows, entropy all.
 """
@@ -106,9 +110,28 @@ def _sharded(logits, labels, temperature, group, chunk, want_entropy):
     return torch.cat(lps), (torch.cat(ents) if want_entropy else None)
 
 
+def _hip(logits, labels, temperature, tp_group, want_entropy):
+    """CUDA path: flatten, pad the labels of the shape quirk with -1 (= no label), run the HIP operator."""
+    from . import ops
+    if tp_group is None:
+        x2, l1 = _rows(logits, labels)
+    else:
+        x2, l1 = logits.reshape(-1, logits.shape[-1]), labels.reshape(-1)
+    R, n_lab = x2.shape[0], l1.shape[0]
+    lab = l1.to(torch.long)
+    if n_lab < R:
+        lab = torch.cat([lab, lab.new_full((R - n_lab,), -1)])
+    lp, ent = ops.logprob_entropy(x2, lab.contiguous(), temperature, want_entropy, tp_group)
+    lp = lp[:n_lab].reshape(labels.shape)
+    return lp, (ent.reshape(logits.shape[:-1]) if want_entropy else None)
+
+
 def gather_logprobs(logits: torch.Tensor, labels: torch.Tensor, temperature: float = 1.0,
                     tp_group: Optional["dist.ProcessGroup"] = None, chunk_size: int = 1024) -> torch.Tensor:
-    if tp_group is not None and dist.get_world_size(tp_group) > 1:
+    sharded = tp_group is not None and dist.get_world_size(tp_group) > 1
+    if logits.is_cuda:
+        return _hip(logits, labels, temperature, tp_group if sharded else None, False)[0]
+    if sharded:
         return _sharded(logits, labels, temperature, tp_group, chunk_size, False)[0]
     assert logits.shape[0] > 0, "Input logits must have at least one element"
     x2, l1 = _rows(logits, labels)
@@ -118,7 +141,10 @@ def gather_logprobs(logits: torch.Tensor, labels: torch.Tensor, temperature: flo
 
 def gather_logprobs_entropy(logits: torch.Tensor, labels: torch.Tensor, temperature: float = 1.0,
                             tp_group: Optional["dist.ProcessGroup"] = None, chunk_size: int = 1024) -> Tuple[torch.Tensor, torch.Tensor]:
-    if tp_group is not None and dist.get_world_size(tp_group) > 1:
+    sharded = tp_group is not None and dist.get_world_size(tp_group) > 1
+    if logits.is_cuda:
+        return _hip(logits, labels, temperature, tp_group if sharded else None, True)
+    if sharded:
         return _sharded(logits, labels, temperature, tp_group, chunk_size, True)
     assert logits.shape[0] > 0, "Input logits must have at least one element"
     x2, l1 = _rows(logits, labels)

@@ -28,14 +28,22 @@ extern "C" {
 #define DTA_EUNSUPPORTED (-2)/* head_dim != 128, dtype not bf16/f16, Hq % Hkv != 0 ...  */
 #define DTA_EALIGN (-3)      /* pointer or stride not 16-byte aligned */
 #define DTA_ELAUNCH (-4)     /* hipGetLastError() after the launch was not hipSuccess */
+#define DTA_EPRIOR (-5)      /* a HIP error was ALREADY pending on this thread when the entry point was called (an earlier
+                              * asynchronous kernel fault or an unchecked runtime call): nothing was launched and the error
+                              * is left in place; dta_take_pending_error() names and clears it */
 
 #define DTA_BF16 0
 #define DTA_F16 1
+#define DTA_F32 2            /* log-prob / entropy kernels only (the reference calls them on logits.float(), vocab_parallel.py:16,24) */
 
 #define DTA_QTILE 128        /* query rows per workgroup (fwd / dQ kernels)  */
-#define DTA_KTILE 128        /* key rows per workgroup (dK/dV kernel): 4 waves x 32 keys */
+#define DTA_KTILE 128        /* key rows per workgroup (dK/dV kernel): 8 waves = 2 groups x (4 waves x 32 keys) sharing the keys */
 
 int dta_version(void);
+
+/* Name (into msg[cap], NUL-terminated) and CLEAR the HIP error pending on the calling thread; returns its hipError_t value
+ * (0 = none).  After an asynchronous kernel fault the context stays unusable - clearing only lets the caller report it. */
+int dta_take_pending_error(char* msg, int32_t cap);
 
 /* ---------------------------------------------------------------------------------------------
  * Trie build kernels (integer, bit-exact, HBM-bound)
@@ -44,7 +52,7 @@ int dta_version(void);
 /* Adjacent longest-common-prefix of S sequences held in one int64 `tokens` buffer: sequence i (in
  * the order to be compared) is tokens[starts[i] .. starts[i]+lens[i]).  out_lcp[i] = lcp(seq i,
  * seq i+1); *out_unsorted += number of adjacent pairs that violate lexicographic order
- * (seq_i[lcp] > seq_{i+1}[lcp]).  The caller zeroes out_unsorted.
+ * (seq_i[lcp] > seq_{i+1}[lcp]).  The caller zeroes out_unsorted.  S = 0 or 1: nothing to compare, DTA_OK.
  * Replaces token_trie.py:6-10 (_lcp_torch), the order check token_trie.py:24-30 and the
  * recomputation after a permutation, token_trie.py:94.  */
 int dta_lcp_adjacent(const int64_t* tokens, const int64_t* starts, const int32_t* lens, int32_t S,
@@ -142,21 +150,30 @@ int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v, const void
                          void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Log-prob / entropy over vocabulary rows (HBM-bound).  logits: [R, V] bf16/f16 with row_stride
- * elements between rows.  fwd writes (fp32) lse[r] = ln sum_j exp(x_j/T), entropy[r] (may be NULL) and
- * logprob[r] = x[labels[r]]/T - lse[r] (may be NULL).  bwd OVERWRITES logits with dLoss/dlogits given
- * g_logprob[r] (for labels[r]), g_extra[r] (sum of the gradients of any further log-probs picked from
- * row r: a fork node has one per child; their one-hot terms are added by the caller) and g_entropy[r].
- * Replaces vocab_parallel.py:13-27 (_gather_logprobs[_entropy]) and its autograd backward.  */
-int dta_logprob_entropy_fwd(const void* logits, const int64_t* labels, float* lse, float* entropy, float* logprob,
+ * Log-prob / entropy over vocabulary rows (HBM-bound).  logits: [R, V] bf16 / f16 / f32 with row_stride elements
+ * between rows (multiple of 8; base 16-byte aligned, 32-byte for f32).  All statistics are fp32.
+ * fwd writes lse[r] = ln sum_j exp(x_j/T), entropy[r] (may be NULL) and logprob[r] = x[labels[r]]/T - lse[r] (may be
+ * NULL; a label outside [0, V) yields 0).  EXTRA picks: a trie node with several children predicts one token per child
+ * (the fork-position logits of tree_training_engine.py:205-209, 217-220, 369-372).  They come as a CSR over the rows:
+ * extra_ptr[R+1] (int32, absolute indices into the extra arrays; NULL = none), extra_labels[F]; the forward writes
+ * extra_logprob[f] = x[extra_labels[f]]/T - lse[row of f].
+ * bwd writes dLoss/dlogits to `dlogits` (== logits: in place) given g_logprob[r], g_extra_logprob[F] and g_entropy[r]
+ * (each may be NULL), including the one-hot terms of every pick.
+ * Replaces vocab_parallel.py:13-27 (_gather_logprobs[_entropy]) with its autograd backward, and the torch indexing of
+ * the fork rows.  */
+int dta_logprob_entropy_fwd(const void* logits, const int64_t* labels, const int32_t* extra_ptr, const int64_t* extra_labels,
+                            float* lse, float* entropy, float* logprob, float* extra_logprob,
                             int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream);
 /* Vocab-sharded forward: raw per-shard statistics stats[R][4] = {m, s, t, picked} (log2 domain of x*log2(e)/T;
- * labels shard-local, -1 = owned by another rank) for the cross-rank combine of vocab_parallel.py:125-160, 258-300. */
-int dta_logprob_entropy_shard_stats(const void* logits, const int64_t* labels, float* stats,
+ * labels shard-local, -1 = owned by another rank; extra_picked[F] likewise raw x/T or 0) for the cross-rank combine of
+ * vocab_parallel.py:125-160, 258-300. */
+int dta_logprob_entropy_shard_stats(const void* logits, const int64_t* labels, const int32_t* extra_ptr, const int64_t* extra_labels,
+                                    float* stats, float* extra_picked,
                                     int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream);
-int dta_logprob_entropy_bwd(void* logits_inout, const int64_t* labels, const float* lse, const float* entropy,
-                            const float* g_logprob, const float* g_extra, const float* g_entropy,
-                            int32_t R, int32_t V, int64_t row_stride, float temperature, int32_t dtype, void* stream);
+int dta_logprob_entropy_bwd(const void* logits, void* dlogits, const int64_t* labels, const int32_t* extra_ptr, const int64_t* extra_labels,
+                            const float* lse, const float* entropy,
+                            const float* g_logprob, const float* g_extra_logprob, const float* g_entropy,
+                            int32_t R, int32_t V, int64_t row_stride, int64_t out_row_stride, float temperature, int32_t dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused row kernels of the decoder layer (HBM-bound; bf16/f16 storage, fp32 math).  They restate the
@@ -169,7 +186,7 @@ int dta_logprob_entropy_bwd(void* logits_inout, const int64_t* labels, const flo
  * (x_out of the forward), `dres` (may be NULL) the gradient arriving on the residual stream, added to dx. */
 int dta_rmsnorm_fwd(const void* x, const void* delta, const void* w, void* x_out, void* y, float* rstd,
                     int32_t R, int32_t H, float eps, int32_t dtype, void* stream);
-int dta_rmsnorm_bwd_blocks(int32_t R);   /* rows of the dw_partial workspace [blocks, H] (float); caller sums dim 0 */
+int dta_rmsnorm_bwd_blocks(int32_t R);   /* rows of the dw_partial workspace [blocks, H] (float); caller sums dim 0.  H % 8 == 0; bwd: H <= 8192 */
 int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dres, const float* rstd, void* dx, float* dw_partial,
                     int32_t R, int32_t H, int32_t dtype, void* stream);
 /* x: [T, NH, 128] with token stride x_stride_t; cos_sin: float [T, 128] = {cos[64], sin[64]} of the token's

@@ -2,6 +2,8 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import hostmirror
 from dynamictreeattn_amd import packing, synth, ops
 from oracle import trie_oracle as to
 from oracle.attn_oracle import tree_attention as ref_attn, rect_causal_attention
@@ -12,7 +14,7 @@ dev = torch.device("cuda:0")
 def run_case(seqs, Hq=4, Hkv=2, dtype=torch.bfloat16, tag=""):
     t = to.TokenTrieOracle([np.array(s) for s in seqs]); t.backward_permute()
     plan = packing.plan_segments(t.lens, t.lcp_lens)
-    _, depth, parent, se = packing.expand_plan_host(plan)
+    _, depth, parent, se = hostmirror.expand_plan_host(plan)
     T = plan.T
     q = torch.randn(T, Hq, 128); k = torch.randn(T, Hkv, 128); v = torch.randn(T, Hkv, 128); do = torch.randn(T, Hq, 128)
     qd, kd, vd, dod = [x.to(dtype).to(dev) for x in (q, k, v, do)]

@@ -56,7 +56,7 @@ def _cpu_attention(q, k, v, meta, scale=None):
     return attn_oracle.tree_attention(q, k, v, se, scale)[0]
 
 
-def _cpu_lm_head_rows(h, W, next_tok, fork_rows, fork_tok, fork_bounds, want_entropy, chunk, keep_bytes=None):
+def _cpu_lm_head_rows(h, W, next_tok, fork_ptr, fork_tok, fork_rows, fork_bounds, want_entropy, chunk, keep_bytes=None):
     """Plain-torch stand-in of ops.lm_head_rows (fp32 log-softmax over the full rows)."""
     lp_all = torch.log_softmax(torch.nn.functional.linear(h, W).float(), dim=-1)
     ent = -(lp_all.exp() * lp_all).sum(-1) if want_entropy else None

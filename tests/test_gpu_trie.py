@@ -29,6 +29,13 @@ def test_tokentrie_all_fixture_cases_bit_exact(trie_golden):
         for name in ("forward_permute", "backward_permute"):
             t2 = TokenTrie(synth.as_tensors(synth.make_case(item["case"]))); getattr(t2, name)()
             assert t2.lens == ref[name]["lens"] and t2.lcp_lens == ref[name]["lcp_lens"] and _attach_table(t2) == ref[name]["attach"]
+            # permute() derives the new adjacent LCPs on the host (range minima of the sorted-order kernel output); the kernel
+            # recomputation from the tokens (what token_trie.py:94 does) must give the same integers
+            assert t2.lcp_from_tokens() == t2.lcp_lens, (item["case"], name)
+        t3 = TokenTrie(synth.as_tensors(synth.make_case(item["case"])))
+        t3.random_permute(); assert t3.lcp_from_tokens() == t3.lcp_lens
+        t3.backward_permute(); assert t3.lcp_from_tokens() == t3.lcp_lens          # a permutation of a permuted trie
+        assert sorted(map(tuple, (x.tolist() for x in t3.inputs))) == sorted(map(tuple, (x.tolist() for x in t.inputs)))
 
 
 def test_unsorted_flag_raises_like_reference():
@@ -40,6 +47,11 @@ def test_unsorted_flag_raises_like_reference():
 def test_edge_cases():
     t = TokenTrie(synth.as_tensors([[7]]))
     assert (t.lens, t.lcp_lens, t.n_tokens) == ([1], [], 1)
+    e = TokenTrie([])                                           # the reference returns an empty trie (token_trie.py:52-82)
+    assert (e.inputs, e.attach_lists, e.lens, e.lcp_lens, e.n_sequences, e.n_tokens) == ([], [], [], [], 0, 0)
+    assert e.get_stats("forward")["n_tree_tokens"] == 0
+    with pytest.raises(ValueError):                             # as the reference: CompressedTrie([], []) has len(lcp) != len(lens) - 1 (trie.py:77-78)
+        e.backward_permute()
     seqs = [[1] * 5000, [1] * 4999 + [2], [1] * 1023 + [3], [1] * 1024 + [4], [1] * 1025 + [0]]
     t = TokenTrie(synth.as_tensors(seqs))
     o = to.TokenTrieOracle([np.array(s) for s in seqs])
@@ -87,3 +99,17 @@ def test_preorder_meta_kernel_vs_host_mirror():
             for i, leaf in enumerate(t.inputs):
                 assert torch.equal(tok[pk.paths[i].cpu()], leaf)
             assert int(pk.meta.ktile_qend.max()) == pk.plan.T
+            # the host-planned key-tile query ends (no device->host read) equal the per-tile maximum of the kernel's subtree_end
+            from dynamictreeattn_amd import ops
+            assert torch.equal(pk.meta.ktile_qend.cpu(), ops.ktile_qend_from(pk.subtree_end).cpu())
+
+
+def test_engine_refuses_a_trie_on_another_device_and_fp32():
+    from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine, _PackedTrie
+    from dynamictreeattn_amd import model as m
+    t = TokenTrie(synth.as_tensors([[1, 2, 3], [1, 2, 4]]))
+    with pytest.raises(RuntimeError, match="holds its tokens on"):
+        _PackedTrie(t, torch.device("cuda", 1))                # no second GPU needed: the check is on the device ids
+    cfg = m.make_config(synth.QWEN3_0P6B)
+    with pytest.raises(TypeError, match="bfloat16 / torch.float16"):
+        TreeTrainingEngine(cfg, "cuda:0", torch.float32, 128)    # run.py:122-132 allows fp32; this HIP path states why it does not
