@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
   dsum += __shfl_xor(dsum, 32);
   const float delta = dsum;
   const float lse2 = p.lse_r[(int64_t)hq * p.Tq + qrow_c];
-  if (h == 0 && qrow < p.Tq) p.delta[(int64_t)hq * p.Tq + qrow] = delta;
+  if (h == 0 && qrow < p.Tq) p.delta[(int64_t)hq * p.Tq + qrow] = -delta;    // workspace holds -delta: the dK/dV kernel loads it as the INITIAL dP accumulator
 
   TileIter it; it.runs = p.runs; it.diag_first_q = p.q_offset + q0;
   bool any = true;
@@ -636,74 +636,83 @@ __global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p
     ++ti_n; row_n += 64; q_cur += q_step; d_cur += d_step;                                                 \
     if (ti_n >= ntile) { ti_n = 0; row_n = qbeg - p.q_offset; q_cur += q_wrap; d_cur += d_wrap; c_cur += p.Tq; } }
 
+  // Per-lane LDS byte offsets of every fragment read of this wave group inside a tile buffer, computed once; the tile loop is
+  // unrolled over the two buffers so that the buffer offset is an instruction immediate (no per-tile address VALU).
+  int ar[8], at[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ar[j] = offs.row[j] + grp * (32 * 256); at[j] = offs.tr[j] + grp * (32 * 256); }
+  const int rc_off = (32 * grp + 4 * h) * 4;                            // this lane's first row constant (lse / -delta) inside a buffer
+
+  // one 64-row query tile out of buffer BUFI (compile-time)
+#define KV2_TILE(BUFI)                                                                                     \
+  {                                                                                                        \
+    const int ti = ti_c;                                                                                   \
+    ti_c += 1;                                                                                             \
+    if (ti_c >= ntile) ti_c = 0;                                                                           \
+    if (idx + 1 < total) KV2_DMA(1 - (BUFI))      /* lands while this tile computes; waited for at the tile end */ \
+    const char* tb = smem + (BUFI) * KV2_BUF;                                                              \
+    const char* rc = tb + 2 * TILE_BYTES + rc_off;                                                         \
+    const int qi0 = qbeg + 64 * ti + 32 * grp;                       /* packed index of this group's first row */ \
+    const bool full = (qbeg + 64 * ti >= k0 + KT - 1) && (qbeg + 64 * ti + 63 < se_min);   /* workgroup-uniform: no mask needed */ \
+    /* S starts at 0 (inline constant); dP starts at -delta, read from LDS straight into the accumulator registers:    \
+       p = exp2(c*S - lse),  dS/scale = p * dP'  with dP' = dO.V^T - delta  (the softmax scale of dS goes onto dK once, in the epilogue) */ \
+    f32x16 S, DP;                                                                                          \
+    _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                     \
+      const float4 d4 = *reinterpret_cast<const float4*>(rc + 256 + 32 * gq);                              \
+      DP[4 * gq] = d4.x; DP[4 * gq + 1] = d4.y; DP[4 * gq + 2] = d4.z; DP[4 * gq + 3] = d4.w;              \
+    }                                                                                                      \
+    _Pragma("unroll") for (int g = 0; g < 16; ++g) S[g] = 0.f;                                             \
+    _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                        \
+      const v8 aq = *reinterpret_cast<const v8*>(tb + ar[s]);                                              \
+      const v8 ad = *reinterpret_cast<const v8*>(tb + ar[s] + TILE_BYTES);                                 \
+      const v8 kfs = *reinterpret_cast<const v8*>(kvs + s * 1024 + lane * 16);                             \
+      const v8 vfs = *reinterpret_cast<const v8*>(kvs + 8192 + s * 1024 + lane * 16);                      \
+      S = T::mma(aq, kfs, S); DP = T::mma(ad, vfs, DP);                                                    \
+    }                                                                                                      \
+    float nl[16];                                                                                          \
+    _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                     \
+      const float4 l4 = *reinterpret_cast<const float4*>(rc + 32 * gq);                                    \
+      nl[4 * gq] = l4.x; nl[4 * gq + 1] = l4.y; nl[4 * gq + 2] = l4.z; nl[4 * gq + 3] = l4.w;              \
+    }                                                                                                      \
+    if (full) {                                                                                            \
+      _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                     \
+        const float pv = fast_exp2(__builtin_fmaf(S[g], c, -nl[g]));                                       \
+        S[g] = pv;                                                                                         \
+        DP[g] = pv * DP[g];                                                                                \
+      }                                                                                                    \
+    } else {                                                                                               \
+      _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                     \
+        const int qi = qi0 + 8 * (g >> 2) + 4 * h + (g & 3);                                               \
+        const bool ok = (kidx <= qi) && (qi < se_l);                                                       \
+        const float pv = ok ? fast_exp2(__builtin_fmaf(S[g], c, -nl[g])) : 0.f;                            \
+        S[g] = pv;                                                                                         \
+        DP[g] = pv * DP[g];                                                                                \
+      }                                                                                                    \
+    }                                                                                                      \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                     \
+      const v8 pb = pack_half<DT>(S, s2), sbf = pack_half<DT>(DP, s2);                                     \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                   \
+        const v8 adt = tr_pair<v8>(tb + at[db] + TILE_BYTES + 4096 * s2, tb + at[4 + db] + TILE_BYTES + 4096 * s2); \
+        const v8 aqt = tr_pair<v8>(tb + at[db] + 4096 * s2, tb + at[4 + db] + 4096 * s2);                  \
+        DV[db] = T::mma(adt, pb, DV[db]); DK[db] = T::mma(aqt, sbf, DK[db]);                               \
+      }                                                                                                    \
+    }                                                                                                      \
+    DMA_WAIT(); __syncthreads();                                                                           \
+    ++idx;                                                                                                 \
+  }
+
   {
     int ti_c = 0;
     if (total > 0) KV2_DMA(0)
     DMA_WAIT(); __syncthreads();
-    int cur = 0;
-    for (int idx = 0; idx < total; ++idx) {
-      const int ti = ti_c;
-      ti_c += 1;
-      if (ti_c >= ntile) ti_c = 0;
-      if (idx + 1 < total) KV2_DMA(cur ^ 1)                  // lands while this tile computes; waited for at the tile end
-      const float* lse_s = reinterpret_cast<const float*>(smem + cur * KV2_BUF + 2 * TILE_BYTES); const float* del_s = lse_s + 64;
-      const int qi0 = qbeg + 64 * ti + 32 * grp;                       // packed index of this group's first row
-      const bool full = (qbeg + 64 * ti >= k0 + KT - 1) && (qbeg + 64 * ti + 63 < se_min);   // workgroup-uniform: no mask needed
-      const int sb = cur * KV2_BUF + grp * (32 * 256);
-      int ar[8], at[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { ar[j] = offs.row[j] + sb; at[j] = offs.tr[j] + sb; }
-      f32x16 S, DP;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) { S[g] = 0.f; DP[g] = 0.f; }
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const v8 aq = *reinterpret_cast<const v8*>(smem + ar[s]);
-        const v8 ad = *reinterpret_cast<const v8*>(smem + ar[s] + TILE_BYTES);
-        const v8 kfs = *reinterpret_cast<const v8*>(kvs + s * 1024 + lane * 16);
-        const v8 vfs = *reinterpret_cast<const v8*>(kvs + 8192 + s * 1024 + lane * 16);
-        S = T::mma(aq, kfs, S); DP = T::mma(ad, vfs, DP);
-      }
-      float nl[16], dl[16];
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int ql = 32 * grp + 8 * gq + 4 * h;
-        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + ql);
-        const float4 d4 = *reinterpret_cast<const float4*>(del_s + ql);
-        nl[4 * gq] = l4.x; nl[4 * gq + 1] = l4.y; nl[4 * gq + 2] = l4.z; nl[4 * gq + 3] = l4.w;
-        dl[4 * gq] = d4.x; dl[4 * gq + 1] = d4.y; dl[4 * gq + 2] = d4.z; dl[4 * gq + 3] = d4.w;
-      }
-      if (full) {
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const float pv = fast_exp2(__builtin_fmaf(S[g], c, -nl[g]));
-          S[g] = pv;
-          DP[g] = pv * (DP[g] - dl[g]);
-        }
-      } else {
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int qi = qi0 + 8 * (g >> 2) + 4 * h + (g & 3);
-          const bool ok = (kidx <= qi) && (qi < se_l);
-          const float pv = ok ? fast_exp2(__builtin_fmaf(S[g], c, -nl[g])) : 0.f;
-          S[g] = pv;
-          DP[g] = pv * (DP[g] - dl[g]);
-        }
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const v8 pb = pack_half<DT>(S, s2), sbf = pack_half<DT>(DP, s2);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          const v8 adt = tr_pair<v8>(smem + at[db] + TILE_BYTES + 4096 * s2, smem + at[4 + db] + TILE_BYTES + 4096 * s2);
-          const v8 aqt = tr_pair<v8>(smem + at[db] + 4096 * s2, smem + at[4 + db] + 4096 * s2);
-          DV[db] = T::mma(adt, pb, DV[db]); DK[db] = T::mma(aqt, sbf, DK[db]);
-        }
-      }
-      DMA_WAIT(); __syncthreads();
-      cur ^= 1;
+    int idx = 0;
+    while (idx < total) {
+      KV2_TILE(0)
+      if (idx >= total) break;
+      KV2_TILE(1)
     }
   }
+#undef KV2_TILE
 #undef KV2_DMA
   {
     // group 1 hands its partial sums to group 0 through LDS, 32 accumulators (one d-block of dK and dV) at a time
@@ -737,6 +746,21 @@ __global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p
         const int d = 32 * db + 8 * gq + 4 * h;
         *reinterpret_cast<float4*>(ws + d) = make_float4(DK[db][4 * gq], DK[db][4 * gq + 1], DK[db][4 * gq + 2], DK[db][4 * gq + 3]);
         *reinterpret_cast<float4*>(ws + KT * 128 + d) = make_float4(DV[db][4 * gq], DV[db][4 * gq + 1], DV[db][4 * gq + 2], DV[db][4 * gq + 3]);
+      }
+  } else if (kidx < p.Tk && p.accumulate == 2) {
+    // fp32 accumulation buffers (the grad-KV stack of the block-wise engine: hundreds of adds per row stay exact to fp32)
+    float* dkp = reinterpret_cast<float*>(p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+    float* dvp = reinterpret_cast<float*>(p.dv) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = 32 * db + 8 * gq + 4 * h;
+        float4 a = *reinterpret_cast<const float4*>(dkp + d), b = *reinterpret_cast<const float4*>(dvp + d);
+        a.x += DK[db][4 * gq]; a.y += DK[db][4 * gq + 1]; a.z += DK[db][4 * gq + 2]; a.w += DK[db][4 * gq + 3];
+        b.x += DV[db][4 * gq]; b.y += DV[db][4 * gq + 1]; b.z += DV[db][4 * gq + 2]; b.w += DV[db][4 * gq + 3];
+        *reinterpret_cast<float4*>(dkp + d) = a;
+        *reinterpret_cast<float4*>(dvp + d) = b;
       }
   } else if (kidx < p.Tk) {
     e* dkp = reinterpret_cast<e*>(p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
@@ -794,6 +818,13 @@ __global__ __launch_bounds__(256) void tree_attn_bwd_dkv_finalize_kernel(AttnPar
       const float4 v = *reinterpret_cast<const float4*>(ws0 + j * slab_st + (int64_t)i * 4);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
+    if (p.accumulate == 2) {
+      float* outf = reinterpret_cast<float*>(which ? p.dv : p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh + d;
+      float4 o = *reinterpret_cast<const float4*>(outf);
+      o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+      *reinterpret_cast<float4*>(outf) = o;
+      continue;
+    }
     e* out = reinterpret_cast<e*>(which ? p.dv : p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh + d;
     if (p.accumulate) { const v4 o = *reinterpret_cast<const v4*>(out); acc.x += (float)o[0]; acc.y += (float)o[1]; acc.z += (float)o[2]; acc.w += (float)o[3]; }
     v4 w; w[0] = (e)acc.x; w[1] = (e)acc.y; w[2] = (e)acc.z; w[3] = (e)acc.w;
@@ -848,7 +879,7 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   if (!q || !k || !v || !out || !dout || !lse || !delta || !dq || !dk || !dv || Tq <= 0 || Tk <= 0 || Hq <= 0 || Hkv <= 0 || q_offset < 0) return DTA_EINVAL;
   if ((runs == nullptr) != (run_ptr == nullptr)) return DTA_EINVAL;
   if (dkv_units && (n_units <= 0 || n_splits < 0 || (n_splits > 0 && (!dkv_splits || !dkv_ws)))) return DTA_EINVAL;
-  if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16)) return DTA_EUNSUPPORTED;
+  if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16) || accumulate < 0 || accumulate > 2) return DTA_EUNSUPPORTED;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) ||
       (q_st | q_sh | kv_st | kv_sh | v_st | v_sh | o_st | o_sh | dq_st | dq_sh | dkv_st | dkv_sh) % 8 != 0) return DTA_EALIGN;
   if (q_st < 0 || o_st < 0 || q_st > (1 << 24) || o_st > (1 << 24)) return DTA_EUNSUPPORTED;   // 64-row tile = scalar base + 32-bit lane offset

@@ -111,7 +111,7 @@ def _cfg_of(model):
     return c.num_attention_heads, c.num_key_value_heads, D, float(getattr(c, "rms_norm_eps", 1e-6)), float(theta)
 
 
-def _layer_forward(layer, res, delta, cos_sin, meta, Hq, Hkv, D, eps):
+def _layer_forward(layer, res, delta, cos_sin, attn, Hq, Hkv, D, eps):
     """One decoder layer over the packed rows.  The hidden state enters as (residual stream, pending update)
     so that each residual add is fused into the RMSNorm that follows it.  hipBLASLt GEMMs through torch;
     everything between them is a HIP kernel of this package."""
@@ -133,7 +133,7 @@ def _layer_forward(layer, res, delta, cos_sin, meta, Hq, Hkv, D, eps):
         qn = getattr(a, "q_norm", None); kn = getattr(a, "k_norm", None)
         q = ops.qk_norm_rope(q, qn.weight if qn is not None else None, cos_sin, eps)
         k = ops.qk_norm_rope(k, kn.weight if kn is not None else None, cos_sin, eps)
-    o = ops.tree_attention(q, k, v, meta)
+    o = attn(q, k, v)                   # ops.tree_attention over a packed trie, or ops.stack_attention over the KV stack
     attn_out = ops.linear(o.reshape(T, Hq * D), a.o_proj.weight)
     res, h = ops.add_rms_norm(res, attn_out, layer.post_attention_layernorm.weight, eps)
     m = layer.mlp
@@ -182,24 +182,27 @@ class _LayerRecompute(torch.autograd.Function):
 
 
 def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta, checkpoint_layers: bool = False,
-                         attn_keep_bytes: int = 0) -> torch.Tensor:
+                         attn_keep_bytes: int = 0, attn_of_layer=None) -> torch.Tensor:
     """Final-norm hidden states [T, hidden] of the packed tokens.  `model` is a Qwen3TreeLM or an HF
     Qwen2/Qwen3 *ForCausalLM (duck-typed).  `checkpoint_layers`: recompute each layer in the backward;
-    `attn_keep_bytes`: HBM budget for attention outputs kept across that recomputation (layers are served first to last)."""
+    `attn_keep_bytes`: HBM budget for attention outputs kept across that recomputation (layers are served first to last).
+    `attn_of_layer(l)` -> callable (q, k, v) -> o replaces the packed tree attention (the block-wise engine passes the
+    stack form bound to layer l's KV stack; `meta` is unused then)."""
     Hq, Hkv, D, eps, theta = _cfg_of(model)
     body = model.model
     res, delta = F.embedding(tokens, body.embed_tokens.weight), None
     cos_sin = ops.rope_cos_sin(depth, D, theta)
     per_layer = tokens.shape[0] * Hq * (D * res.element_size() + 4)             # out + lse of one layer
-    for layer in body.layers:
+    for li, layer in enumerate(body.layers):
+        attn = attn_of_layer(li) if attn_of_layer is not None else (lambda q, k, v: ops.tree_attention(q, k, v, meta))
         if checkpoint_layers and torch.is_grad_enabled():
-            keep = attn_keep_bytes >= per_layer
+            keep = attn_of_layer is None and attn_keep_bytes >= per_layer
             if keep:
                 attn_keep_bytes -= per_layer
-            fn = (lambda layer_: lambda r_, d_: _layer_forward(layer_, r_, d_, cos_sin, meta, Hq, Hkv, D, eps))(layer)
+            fn = (lambda layer_, attn_: lambda r_, d_: _layer_forward(layer_, r_, d_, cos_sin, attn_, Hq, Hkv, D, eps))(layer, attn)
             res, delta = _LayerRecompute.apply(fn, keep, res, delta)
         else:
-            res, delta = _layer_forward(layer, res, delta, cos_sin, meta, Hq, Hkv, D, eps)
+            res, delta = _layer_forward(layer, res, delta, cos_sin, attn, Hq, Hkv, D, eps)
     return ops.add_rms_norm(res, delta, body.norm.weight, eps)[1]
 
 

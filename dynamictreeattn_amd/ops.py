@@ -144,7 +144,7 @@ def attn_bwd_raw(q, k, v, out, dout, lse, meta: TreeAttnMeta, scale: float, dk=N
         return lib().dta_tree_attn_bwd_ex(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
                                           ptr(meta.subtree_end), ptr(meta.run_ptr), ptr(meta.runs), ptr(meta.ktile_qend),
                                           Tq, Tk, meta.q_offset, Hq, Hkv, D, qs, qh, ks, kh, vs, vh, os_, oh, dqs, dqh, dks, dkh,
-                                          float(scale), _DT[q.dtype], 1 if accumulate else 0, which,
+                                          float(scale), _DT[q.dtype], int(accumulate), which,
                                           ptr(units), n_units, ptr(splits) if n_splits else None, n_splits, ptr(ws), stream)
     tm = KernelTimer.active
     with _on(q, k, v, out, dout, lse, dk, dv, meta.subtree_end, units) as stream:
@@ -200,6 +200,43 @@ class _TreeAttention(torch.autograd.Function):
         q, k, v, out, lse = ctx.saved_tensors
         dq, dk, dv = attn_bwd_raw(q, k, v, out, dout, lse, ctx.meta, ctx.scale)
         return dq, dk, dv, None, None
+
+
+class _StackAttention(torch.autograd.Function):
+    """Attention of a block of B new rows at stack positions [start, start+B) over the KV STACK in place (the form of
+    tree_training_engine.py:171-186, 339-353 without `DynamicCache`/`torch.cat`): forward writes the block's K/V into the
+    stack rows and attends rows [0, start+B) rectangular-causally; backward adds this block's dK/dV into the fp32 grad
+    stacks for ALL rows [0, start+B) (`accumulate = 2`; replaces the prefix-sized `.grad` tensors and `+=` of tte:447-451)
+    and returns, as the gradient of the block's own K/V, what the grad stack now holds for its rows — i.e. the
+    contributions of every already-popped descendant plus the block's own."""
+
+    @staticmethod
+    def forward(ctx, q, k_new, v_new, kst, vst, gk, gv, start, scale):
+        B = q.shape[0]
+        end = start + B
+        kst[start:end].copy_(k_new); vst[start:end].copy_(v_new)
+        meta = stack_meta(start)
+        out, lse, _, _ = attn_fwd_raw(q, kst[:end], vst[:end], meta, scale)
+        ctx.save_for_backward(q, out, lse)
+        ctx.stacks, ctx.meta, ctx.scale, ctx.span = (kst, vst, gk, gv), meta, scale, (start, end)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, out, lse = ctx.saved_tensors
+        kst, vst, gk, gv = ctx.stacks
+        start, end = ctx.span
+        dq, _, _ = attn_bwd_raw(q, kst[:end], vst[:end], out, dout, lse, ctx.meta, ctx.scale, dk=gk[:end], dv=gv[:end], accumulate=2)
+        return dq, gk[start:end].to(q.dtype), gv[start:end].to(q.dtype), None, None, None, None, None, None
+
+
+def stack_attention(q, k_new, v_new, kst, vst, gk, gv, start: int, scale: Optional[float] = None):
+    """q [B,Hq,128], k_new/v_new [B,Hkv,128] at stack positions start..start+B-1; kst/vst [cap,Hkv,128] (model dtype),
+    gk/gv [cap,Hkv,128] fp32 grad stacks (may be None under no_grad) -> out [B,Hq,128]."""
+    if q.dtype not in _DT:
+        raise TypeError("stack_attention supports bf16 / f16 (got %s)" % q.dtype)
+    scale = q.shape[-1] ** -0.5 if scale is None else scale
+    return _StackAttention.apply(q, k_new, v_new, kst, vst, gk, gv, start, scale)
 
 
 def tree_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, meta: TreeAttnMeta, scale: Optional[float] = None) -> torch.Tensor:

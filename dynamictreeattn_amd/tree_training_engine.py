@@ -187,6 +187,9 @@ class TreeTrainingEngine:
         self.last_packed: Optional[_PackedTrie] = None
         self.head_chunk = 2048
         self.checkpoint_layers: Optional[bool] = None    # None = decide from free HBM
+        self.mode = "auto"                               # "packed" (one pass), "stack" (block-wise push/pop walk), "auto" (by footprint)
+        self.memory_budget_bytes: Optional[int] = None   # activation budget for "auto"; None = 80 % of the free HBM at call time
+        self.last_mode: Optional[str] = None             # what the last backward() ran ("packed" / "packed+recompute" / "stack[B]")
         self.attn_keep_fraction = 0.25                   # of free HBM, for attention outputs kept across layer recomputation
         self.tp_group = None                             # set to a process group to split the LM-head vocabulary across it
 
@@ -213,6 +216,48 @@ class TreeTrainingEngine:
             return False
         free, _ = torch.cuda.mem_get_info(self.device)
         return need > 0.6 * free
+
+    def _per_token_layer_bytes(self, model) -> int:
+        c = model.config
+        D = getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads
+        return 2 * (10 * c.hidden_size + 4 * c.intermediate_size + 4 * (c.num_attention_heads + c.num_key_value_heads) * D)
+
+    def _budget(self) -> Optional[int]:
+        if self.memory_budget_bytes is not None:
+            return int(self.memory_budget_bytes)
+        if self.device.type != "cuda":
+            return None
+        free, _ = torch.cuda.mem_get_info(self.device)
+        return int(0.8 * free)
+
+    def _stack_block_rows(self, model, T: int, block_size: Optional[int]) -> Optional[int]:
+        """None: the packed one-pass engine fits (possibly with per-layer recomputation).  Else the row budget of a block of the
+        block-wise walk: at least the caller's `block_size` (the reference's memory knob, tte:489-513), more when HBM allows."""
+        if self.mode == "packed":
+            return None
+        budget = self._budget()
+        per_layer = self._per_token_layer_bytes(model)
+        c = model.config
+        if self.mode != "stack":
+            if budget is None:
+                return None
+            # one pass with per-layer recomputation keeps two hidden rows per token and layer + one layer's activations + the head
+            need = T * (2 * 2 * c.hidden_size * self.n_layers + 2 * per_layer)
+            if need <= budget:
+                return None
+        bs = block_size or 2048
+        if budget is None:
+            return bs
+        rows = int(0.5 * budget / max(per_layer * self.n_layers, 1)) // 256 * 256
+        return int(max(bs, min(rows, 16384)))
+
+    def _backward_stack(self, model, token_trie, loss_fn, block_rows: int) -> float:
+        from .stack_engine import StackWalk
+        walk = StackWalk(model, token_trie, self.device, self.dtype, block_rows, self.head_chunk, self.tp_group)
+        total = walk.run(loss_fn)
+        self.last_mode = f"stack[{block_rows}]x{walk.n_blocks}"
+        self.cur_len = 0
+        return float(total.item()) if total is not None else 0.0
 
     def _attn_keep_bytes(self) -> int:
         """HBM budget for attention outputs kept across the per-layer recomputation (model.py:_LayerRecompute): a quarter
@@ -265,9 +310,16 @@ class TreeTrainingEngine:
         self.forkpos_list = _get_forkpos(lens, token_trie.lcp_lens, block_size)
         if token_trie.n_sequences == 0:          # an empty bin of a data-parallel step: no loss, no gradient (the caller still reduces)
             return 0.0
+        n_tree = sum(token_trie.lens) - sum(token_trie.lcp_lens)
+        rows = self._stack_block_rows(model, n_tree, block_size)
+        if rows is not None:
+            longest = max(token_trie.lens)
+            assert longest <= self.max_seq_len, f"Exceeds max_seq_len: cur_len=0, new_tokens={longest}, max={self.max_seq_len}"
+            return self._backward_stack(model, token_trie, loss_fn, rows)
         packed = self._pack(token_trie)
         chunk = min(self.head_chunk, block_size) if block_size else self.head_chunk
         ckpt = self._should_checkpoint(model, packed.plan.T)
+        self.last_mode = "packed+recompute" if ckpt else "packed"
         h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, ckpt, self._attn_keep_bytes() if ckpt else 0)
         lp, ent = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, True, max(chunk, 1),
                                          packed.fork_child, packed.fork_parent, self.tp_group)

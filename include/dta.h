@@ -118,8 +118,10 @@ int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v, void* out,
  * (2) per key tile of DTA_KTILE keys: dk, dv summed over the query range
  * [max(key0, q_offset), ktile_qend[tile]) and over the Hq/Hkv query heads of the group — no
  * cross-workgroup reduction, no atomics, bitwise reproducible.  ktile_qend[j] = max subtree_end
- * over the tile's keys (NULL: q_offset + Tq).  `accumulate` != 0 adds into dk/dv (the grad-KV
- * stack of tree_training_engine.py:447-451) instead of overwriting.  delta: [Hq, Tq] float workspace.
+ * over the tile's keys (NULL: q_offset + Tq).  `accumulate`: 0 overwrites dk/dv; 1 adds into them (the grad-KV
+ * stack of tree_training_engine.py:447-451; model dtype, rounded after every add as the reference's `+=`); 2 adds into
+ * FP32 buffers (dk/dv are float*, strides in floats) so that the hundreds of adds a root-side row receives in the
+ * block-wise engine are not rounded to 16 bits each time.  delta: [Hq, Tq] float workspace.
  * Replaces torch.autograd.backward through the attention backend, tree_training_engine.py:440.  */
 int dta_tree_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                       const float* lse, float* delta, void* dq, void* dk, void* dv,

@@ -57,12 +57,42 @@ def _cpu_attention(q, k, v, meta, scale=None):
 
 
 def _cpu_lm_head_rows(h, W, next_tok, fork_ptr, fork_tok, fork_rows, fork_bounds, want_entropy, chunk, keep_bytes=None):
-    """Plain-torch stand-in of ops.lm_head_rows (fp32 log-softmax over the full rows)."""
+    """Plain-torch stand-in of ops.lm_head_rows (fp32 log-softmax over the full rows); a label < 0 = no label (0)."""
     lp_all = torch.log_softmax(torch.nn.functional.linear(h, W).float(), dim=-1)
     ent = -(lp_all.exp() * lp_all).sum(-1) if want_entropy else None
-    lp_next = lp_all.gather(-1, next_tok[:, None]).squeeze(-1)
+    lp_next = lp_all.gather(-1, next_tok.clamp(min=0)[:, None]).squeeze(-1) * (next_tok >= 0)
     lp_fork = lp_all[fork_rows, fork_tok] if fork_rows.numel() else lp_all.new_zeros(0)
     return lp_next, lp_fork, ent
+
+
+class _CpuStackAttention(torch.autograd.Function):
+    """Stand-in of ops._StackAttention with the same side effects: K/V written into the stack rows, dK/dV ADDED into the fp32
+    grad stacks for all rows [0, end), and the grad-stack rows of the block returned as the gradient of its own K/V."""
+
+    @staticmethod
+    def forward(ctx, q, k_new, v_new, kst, vst, gk, gv, start, scale):
+        end = start + q.shape[0]
+        kst[start:end].copy_(k_new); vst[start:end].copy_(v_new)
+        ctx.save_for_backward(q)
+        ctx.stacks, ctx.span, ctx.scale = (kst, vst, gk, gv), (start, end), scale
+        return attn_oracle.rect_causal_attention(q.transpose(0, 1), kst[:end].transpose(0, 1), vst[:end].transpose(0, 1), start, scale)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (q,) = ctx.saved_tensors
+        kst, vst, gk, gv = ctx.stacks
+        start, end = ctx.span
+        with torch.enable_grad():
+            q_, k_, v_ = (t.detach().clone().requires_grad_(True) for t in (q, kst[:end], vst[:end]))
+            out = attn_oracle.rect_causal_attention(q_.transpose(0, 1), k_.transpose(0, 1), v_.transpose(0, 1), start, ctx.scale)
+            dq, dk, dv = torch.autograd.grad(out, (q_, k_, v_), dout)
+        gk[:end] += dk.float(); gv[:end] += dv.float()
+        return dq, gk[start:end].to(q.dtype), gv[start:end].to(q.dtype), None, None, None, None, None, None
+
+
+def _cpu_stack_attention(q, k_new, v_new, kst, vst, gk, gv, start, scale=None):
+    scale = q.shape[-1] ** -0.5 if scale is None else scale
+    return _CpuStackAttention.apply(q, k_new, v_new, kst, vst, gk, gv, start, scale)
 
 
 def _cpu_rms_norm(x, w, eps):
@@ -104,6 +134,7 @@ def install(monkeypatch):
     monkeypatch.setattr(token_trie, "_device_trie_arrays", _cpu_trie_arrays)
     monkeypatch.setattr(tree_training_engine._PackedTrie, "_expand", _cpu_expand)
     monkeypatch.setattr(ops, "tree_attention", _cpu_attention)
+    monkeypatch.setattr(ops, "stack_attention", _cpu_stack_attention)
     monkeypatch.setattr(ops, "lm_head_rows", _cpu_lm_head_rows)
     monkeypatch.setattr(ops, "rms_norm", _cpu_rms_norm)
     monkeypatch.setattr(ops, "add_rms_norm", _cpu_add_rms_norm)

@@ -1,6 +1,6 @@
 """N>1 path on CPU: two gloo ranks on loopback.  (1) trie-sharded data parallelism: every rank
 partitions the same global batch with LB_by_DFS_and_TM, runs its bin, gradients are summed with
-dp.allreduce_grads and must equal the single-process full-batch gradients recorded from the
+dp.allreduce_grads / dp.GradReducer and must equal the single-process full-batch gradients recorded from the
 reference (tests/golden/engine_tiny.pt).  (2) the vocab-sharded logprob/entropy branch against the
 unsharded one and the reference's recorded values."""
 import os
@@ -24,7 +24,7 @@ def _init(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
-def _dp_worker(rank, world, port, name, q, overlapped=False):
+def _dp_worker(rank, world, port, name, q, overlapped=False, one_leaf=False):
     import sys
     sys.path.insert(0, os.path.dirname(__file__)); sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
     import hostmirror
@@ -44,16 +44,22 @@ def _dp_worker(rank, world, port, name, q, overlapped=False):
     model = Qwen3TreeLM(cfg).load_named(mo.init_weights(cfg, seed=case["wseed"]))
     seqs = synth.as_tensors(synth.make_case(case["data"]))
     att = [{"w_logprobs": -1.0 - 0.01 * i, "w_entropy": 0.1 + 0.003 * i} for i in range(len(seqs))]
+    if one_leaf:                      # fewer leaves than ranks: the balancer leaves rank 1's bin EMPTY (it must still reduce)
+        seqs, att = seqs[:1], att[:1]
     ids = dp.my_bin(seqs, rank, world, "backward", 2048)
-    t = token_trie.TokenTrie([seqs[i] for i in ids], [att[i] for i in ids]); t.backward_permute()
+    t = token_trie.TokenTrie([seqs[i] for i in ids], [att[i] for i in ids])
+    if ids:
+        t.backward_permute()
     eng = tree_training_engine.TreeTrainingEngine(model.config, "cpu", torch.float32, 4096)
     if overlapped:
-        # tiny buckets: several collectives are in flight while the backward is still running; a second step re-uses the hooks
-        red = dp.OverlappedGradAllReduce(model.parameters(), bucket_bytes=20000)
+        # tiny buckets: several collectives are in flight while the backward is still running; a second step re-uses the hooks;
+        # every param.grad is a view of a persistent flat buffer that is reduced in place
+        red = dp.GradReducer(model.parameters(), bucket_bytes=20000)
         assert len(red.buckets) > 2
         for _ in range(2):
-            model.zero_grad(set_to_none=True)
+            red.zero_grad()
             red.start(); loss = eng.backward(model, t, mo.default_loss, 2048); red.finish()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in red._views)
         red.close()
     else:
         loss = eng.backward(model, t, mo.default_loss, 2048)
@@ -81,6 +87,32 @@ def test_trie_sharded_dp_grads_equal_full_batch(name, overlapped):
     assert abs(loss - gold["bwd_bs2048_loss"]) < 2e-4 * abs(loss)
     for n, g in gold["bwd_bs2048_grads"].items():
         assert mo.grad_ratio(g, grads[n]) <= 3e-5, n
+
+
+@pytest.mark.parametrize("overlapped", [False, True])
+def test_dp_with_an_empty_bin_still_reduces(overlapped):
+    """K = 2 ranks, ONE sequence: rank 1's bin is empty.  It runs no backward but issues the same collectives; the reduced
+    gradients on rank 0 equal the single-process gradients of that sequence."""
+    import sys, tempfile
+    sys.path.insert(0, os.path.dirname(__file__))
+    import hostmirror
+    from oracle import model_oracle as mo
+    ctx = mp.get_context("spawn"); q = tempfile.mkdtemp(); port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, "d128_minitau", q, overlapped, True)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    res = [torch.load(os.path.join(q, f"rank{r}.pt"), weights_only=True) for r in range(2)]
+    assert res[0]["ids"] == [0] and res[1]["ids"] == []
+    # reference value: the oracle's dense pass over that one sequence (fp32)
+    from dynamictreeattn_amd import synth
+    case = synth.engine_cases()["d128_minitau"]; cfg = synth.TINY_CFGS[case["cfg"]]
+    w = {k: v.clone().requires_grad_(True) for k, v in mo.init_weights(cfg, seed=case["wseed"]).items()}
+    seq = synth.make_case(case["data"])[0]
+    loss = mo.dense_backward(cfg, w, [seq], [{"w_logprobs": -1.0, "w_entropy": 0.1}], mo.default_loss)
+    assert abs(res[0]["loss"] - float(loss)) < 2e-4 * abs(float(loss))
+    for n, g in res[0]["grads"].items():
+        assert mo.grad_ratio(w[n].grad, g) <= 3e-5, n
 
 
 def _vp_worker(rank, world, port, q):

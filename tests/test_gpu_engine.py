@@ -198,3 +198,57 @@ def test_wide_deep_trie_with_layer_checkpointing(dtype, loss_scale, tol):
     assert abs(lt - ld) < 2e-3 * abs(ld)
     ratios = [mo.grad_ratio(p.grad.float(), gt[n]) for n, p in m.named_parameters()]
     assert max(ratios) < tol, max(ratios)
+
+
+@pytest.mark.parametrize("name", ["d128_minitau", "d128_tree"])
+@pytest.mark.parametrize("bs", [64, 2048])
+def test_blockwise_stack_engine_bf16_vs_reference_fp32(name, bs, eng_gold):
+    """engine.mode = "stack" on the HIP kernels (stack-form attention reading the KV stack in place, dK/dV accumulated into fp32
+    grad stacks, pending picks through the log-prob kernels' extra-label CSR) against the reference's recorded fp32 gradients."""
+    m, seqs = _setup(name, torch.bfloat16); g = eng_gold[name]
+    t = TokenTrie(seqs, _att(len(seqs))); t.backward_permute()
+    e = TreeTrainingEngine(m.config, DEV, torch.bfloat16, max(map(len, seqs)))
+    e.mode = "stack"
+    loss = e.backward(m, t, mo.default_loss, bs)
+    assert e.last_mode.startswith("stack[")
+    assert abs(loss - g["bwd_bs2048_loss"]) < 1e-2 * abs(loss)
+    ratios = {n: mo.grad_ratio(g["bwd_bs2048_grads"][n], p.grad.float().cpu()) for n, p in m.named_parameters()}
+    assert max(ratios.values()) <= REF_BF16_BOUND, max(ratios.items(), key=lambda kv: kv[1])
+    assert float(np.median(list(ratios.values()))) <= 2.55e-2
+
+
+QWEN3_4B_LAYER = dict(vocab_size=151936, hidden_size=2560, intermediate_size=9728, num_hidden_layers=2, num_attention_heads=32,
+                      num_key_value_heads=8, head_dim=128, tie_word_embeddings=True, rms_norm_eps=1e-6, rope_theta=1e6)
+
+
+def test_blockwise_engine_bounds_activation_memory_at_qwen3_4b_geometry():
+    """Qwen3-4B LAYER geometry (hidden 2560, 32 / 8 heads of 128, MLP 9728, full vocabulary; two layers) on a config-5-shaped
+    trie (8 branches x 4096 deep over a 512-token root, T = 29 184 tree tokens).  Stated activation budget: 2 GB.  The one-pass
+    engine predicts 10.5 GB even with per-layer recomputation (2 hidden rows per token and layer + two layers' activations), so
+    "auto" takes the block-wise walk — the reference's `block_size` bound (tte:489-513) — whose blocks fit the budget; its
+    gradients equal the unblocked one-pass engine's within the reference's bf16 bound, at a fraction of the peak memory."""
+    cfg = QWEN3_4B_LAYER
+    m = Qwen3TreeLM.from_named(cfg, mo.init_weights(cfg, seed=2), DEV, torch.bfloat16)
+    seqs = synth.as_tensors(synth.wide(seed=3, V=cfg["vocab_size"], root=512, branches=8, depth=4096))
+    att = lambda: [{"w_logprobs": -1.0, "w_entropy": 0.1} for _ in seqs]
+    t = TokenTrie(seqs, att()); t.backward_permute()
+    assert t.get_stats("backward", 2048)["n_tree_tokens"] == 512 + 8 * 3584
+    e = TreeTrainingEngine(m.config, DEV, torch.bfloat16, 4096)
+    torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats(); base = torch.cuda.memory_allocated()
+    e.mode = "packed"
+    l0 = e.backward(m, t, mo.default_loss, 2048)
+    peak_packed = torch.cuda.max_memory_allocated() - base
+    g0 = {n: p.grad.float().clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats(); base = torch.cuda.memory_allocated()
+    e.mode = "auto"; e.memory_budget_bytes = 2 << 30
+    t2 = TokenTrie(seqs, att()); t2.backward_permute()
+    l1 = e.backward(m, t2, mo.default_loss, 2048)
+    peak_stack = torch.cuda.max_memory_allocated() - base
+    assert e.last_mode.startswith("stack["), e.last_mode
+    assert abs(l0 - l1) < 3e-3 * abs(l0)
+    ratios = {n: mo.grad_ratio(g0[n], p.grad.float()) for n, p in m.named_parameters()}
+    assert max(ratios.values()) <= REF_BF16_BOUND, max(ratios.items(), key=lambda kv: kv[1])
+    assert float(np.median(list(ratios.values()))) <= 2.55e-2
+    assert peak_stack < 0.5 * peak_packed, (peak_stack, peak_packed)
+    print(f"peak activation memory: one pass {peak_packed / 2**30:.2f} GiB, block-wise ({e.last_mode}) {peak_stack / 2**30:.2f} GiB")

@@ -49,7 +49,7 @@ def test_kernels_vs_oracle(R, V, temp, dtype):
     assert (ent.cpu() - ent_ref.detach()).abs().max() <= 5e-5 * (1 + ent_ref.abs().max())
     ref = x.grad
     tol = {torch.bfloat16: 1e-2, torch.float16: 2e-3, torch.float32: 2e-5}[dtype]
-    out = torch.empty_like(ld)                                  # out of place first (the caller's logits stay intact) ...
+    out = torch.empty_strided(ld.shape, ld.stride(), dtype=ld.dtype, device=DEV)          # out of place first (the caller's logits stay intact) ...
     ops.logprob_entropy_bwd_raw(ld, labels.to(DEV), lse, ent, glp.to(DEV), gent.to(DEV), temp, ptr_, exl, gex.to(DEV), out=out)
     assert torch.equal(ld.float().cpu(), logits.float())
     assert float((out.float().cpu() - ref).norm() / ref.norm()) <= tol

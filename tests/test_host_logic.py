@@ -95,9 +95,31 @@ def test_balancers_bit_exact(balancer_golden):
             if exp["LB_by_DFS_and_TM"] is not None:
                 lb = dp._leaf_bins_by_DFS_and_TM(tt.lens, tt.lcp_lens, tm, K, mode, bs)
                 assert dp.get_original_bins(tt, lb) == exp["LB_by_DFS_and_TM"], (item["case"], key)
-    args = types.SimpleNamespace(K=2, mode="forward", block_size=None)
-    seqs = synth.as_tensors(synth.make_case(balancer_golden["cases"][3]["case"]))
-    monkey_bins = dp.LB_by_DFS_and_TM(seqs, TreeTimeModel(), args) if False else None       # public entry needs a GPU TokenTrie
+
+
+def test_public_balancer_entries_bit_exact(balancer_golden, monkeypatch):
+    """The PUBLIC entries LB_by_n_tokens / LB_by_TM / LB_by_DFS_and_TM(seqs, tm, args) (data_parallel.py:8-16, 39-56, 81-107) against
+    the reference's recorded bins.  They build their own TokenTrie; here its device steps are the CPU stand-ins (the same entries
+    run on the real HIP TokenTrie in tests/test_gpu_dp.py)."""
+    from dynamictreeattn_amd import token_trie
+    orig = token_trie.TokenTrie.__init__
+    monkeypatch.setattr(token_trie.TokenTrie, "__init__", lambda self, *a, **kw: orig(self, *a, **{**kw, "device": CPU}))
+    n = 0
+    for item in balancer_golden["cases"]:
+        seqs = synth.as_tensors(synth.make_case(item["case"]))
+        for key, exp in item["bins"].items():
+            K, mode, bs, kind = key.split("_")
+            K = int(K[1:]); bs = None if bs == "None" else int(bs)
+            tm = TreeTimeModel()
+            if kind == "tm":
+                tm.coeffs = np.array([3.0e-3, 1.0e-5, 4.0e-6, 2.0e-7, 1.5e-9])
+            args = types.SimpleNamespace(K=K, mode=mode, block_size=bs)
+            assert dp.LB_by_n_tokens(seqs, K) == exp["LB_by_n_tokens"]
+            if exp["LB_by_TM"] is not None:
+                assert dp.LB_by_TM(seqs, tm, args) == exp["LB_by_TM"], (item["case"], key); n += 1
+            if exp["LB_by_DFS_and_TM"] is not None:
+                assert dp.LB_by_DFS_and_TM(seqs, tm, args) == exp["LB_by_DFS_and_TM"], (item["case"], key); n += 1
+    assert n > 20
 
 
 def test_packing_plan_matches_bruteforce():
@@ -245,6 +267,48 @@ def test_engine_backward_fp32_vs_reference(name, perm, eng_gold):
         assert mo.grad_ratio(g["bwd_bs2048_grads"][n], p.grad) <= 2e-5, (name, n)
     with pytest.raises(AssertionError, match="Exceeds max_seq_len"):
         TreeTrainingEngine(m.config, CPU, torch.float32, 3).backward(m, t, mo.default_loss, 2048)
+
+
+@pytest.mark.parametrize("name", list(synth.engine_cases()))
+@pytest.mark.parametrize("bs,perm", [(7, "ours"), (64, "ours"), (2048, "ours"), (7, "idx"), (33, "random")])
+def test_blockwise_stack_engine_fp32_vs_reference(name, bs, perm, eng_gold):
+    """engine.mode = "stack": the memory-bounded push/pop walk over the KV stack (dynamictreeattn_amd/stack_engine.py — the
+    reference's own schedule, tte:232-616, block_size = rows per popped block) reproduces the reference's recorded loss and
+    every parameter gradient for any block size and leaf order: the side channels (grad-KV stack, g_lp, g_ent, pending picks
+    that replace the fork-position logits) are exact."""
+    m, seqs = _model(name); g = eng_gold[name]
+    t = TokenTrie(seqs, _att(len(seqs)), device=CPU)
+    if perm == "ours":
+        t.backward_permute()
+    elif perm == "random":
+        t.random_permute()
+    eng = TreeTrainingEngine(m.config, CPU, torch.float32, max(map(len, seqs)))
+    eng.mode = "stack"
+    loss = eng.backward(m, t, mo.default_loss, block_size=bs)
+    assert eng.last_mode.startswith("stack[")
+    assert abs(loss - g["bwd_bs2048_loss"]) < 2e-4 * max(1.0, abs(loss))
+    for n, p in m.named_parameters():
+        assert mo.grad_ratio(g["bwd_bs2048_grads"][n], p.grad) <= 3e-5, (name, n)
+    with pytest.raises(AssertionError, match="Exceeds max_seq_len"):
+        e2 = TreeTrainingEngine(m.config, CPU, torch.float32, 3); e2.mode = "stack"
+        e2.backward(m, t, mo.default_loss, 2048)
+
+
+def test_engine_mode_auto_switches_by_footprint():
+    """"auto": one packed pass while the predicted footprint fits the budget, the block-wise walk otherwise (the budget is the
+    free HBM on the GPU; here it is set by hand)."""
+    m, seqs = _model("d16_tree")
+    t = TokenTrie(seqs, _att(len(seqs)), device=CPU); t.backward_permute()
+    eng = TreeTrainingEngine(m.config, CPU, torch.float32, 4096)
+    eng.memory_budget_bytes = 1 << 40
+    l0 = eng.backward(m, t, mo.default_loss, 2048); assert eng.last_mode.startswith("packed")
+    g0 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    eng.memory_budget_bytes = 1 << 10
+    l1 = eng.backward(m, t, mo.default_loss, 16); assert eng.last_mode.startswith("stack[")
+    assert abs(l0 - l1) < 1e-4 * abs(l0)
+    for n, p in m.named_parameters():
+        assert mo.grad_ratio(g0[n], p.grad) <= 3e-5, n
 
 
 def test_engine_accepts_a_huggingface_module_by_duck_typing(eng_gold):
