@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — tree-attn fwd+bwd tokens/s, Qwen3-0.6B bf16, synthetic tau2-16k-shaped tries.
+"""bench.py — tree-attn fwd+bwd tokens/s on synthetic tries (BASELINE.json metric; SURVEY §8d protocol).
 
-One *step* = one pass of the hot path over one batch: every rank takes one bin of the global batch
-(N_ranks tau2-shaped calls merged and partitioned by ``LB_by_DFS_and_TM`` before the clock starts, as
-data_parallel.py does offline), builds its TokenTrie (HIP LCP/leafization), permutes it for backward, runs
-``TreeTrainingEngine.backward`` (HIP tree attention fwd+bwd inside the full model pass) and the
-ranks sum their parameter gradients with one RCCL all-reduce.  Timed sync-to-sync like run.py:90-108;
+One *step* = one pass of the hot path over one batch: build the TokenTrie (HIP LCP / leafization), permute it for backward,
+run ``TreeTrainingEngine.backward`` (HIP tree attention fwd+bwd inside the full model pass), and — for N > 1 — sum the
+parameter gradients over the ranks (RCCL, in place, overlapped with the backward).  Timed sync-to-sync like run.py:90-108;
 metric = Σ original-sequence tokens / wall (run_all.py:156-159), MAX over ranks.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant
-attention kernel, HIP-event timed on the launch stream) and `cpu_baseline` (the oracle's
-restatement of the reference schedule timed on the host cores; N=1 only).
+Legs of one invocation (all in the ONE JSON line rank 0 prints):
+* ``value``            WEAK scaling: step s gives every rank one tau2-shaped call (N calls merged and split by
+                       ``LB_by_DFS_and_TM`` before the clock starts, as data_parallel.py does offline).  No kernel timers run here.
+* ``strong_scaling``   (N > 1) the reference's own DP protocol (exp/exp_dp.py:28-49, exp/calc_time.py:24-42): a FIXED batch of calls,
+                       each split N ways; throughput = Σ n_tokens / Σ_calls max_rank(time), plus the balance Σ t_k / (N · max t_k).
+* ``roofline``         the same steps once more with HIP events around every C-ABI launch (their cost is reported as
+                       ``timer_overhead_frac``): dominant MFMA kernel vs the 2.5 PFLOP/s peak, HBM-bound kernels vs 8 TB/s.
+* ``cpu_baseline``     (N = 1) the oracle's restatement of the reference schedule on the host cores: config 1 and a tau2-shaped sample.
+
+Other workloads: ``--workload wide`` (BASELINE config 5: 64 x 16 384 over a 1 024-token root, fp16), ``--model qwen3-4b``,
+``--vocab-parallel`` (BASELINE config 4: the LM-head vocabulary split over the ranks, vocab_parallel.py:82-396).
 """
 import argparse
 import json
@@ -30,9 +36,14 @@ from dynamictreeattn_amd.token_trie import TokenTrie
 from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine
 
 MODEL_NAME = {"qwen3-0.6b": "Qwen3-0.6B", "qwen3-4b": "Qwen3-4B"}
-PEAK_BF16_TFLOPS = 2500.0          # dense MFMA bf16 peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_TFLOPS = 2500.0               # dense MFMA bf16 / f16 peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0              # HBM3E spec, same table (6 290 GB/s measured copy)
 ATTACH = {"w_logprobs": -1.0, "w_entropy": 0.1}      # run_all.py:11-14
 DKV_KERNEL = "tree_attn_bwd_dkv2_kernel"             # the dominant kernel as rocprofv3 names it (8-wave dK/dV)
+HBM_KERNELS = {"dta_logprob_entropy_fwd": "logprob_entropy_fwd_kernel", "dta_logprob_entropy_bwd": "logprob_entropy_bwd_kernel",
+               "dta_rmsnorm_fwd": "rmsnorm_fwd_kernel", "dta_rmsnorm_bwd": "rmsnorm_bwd_kernel",
+               "dta_qk_norm_rope_fwd": "qk_norm_rope_fwd_kernel", "dta_qk_norm_rope_bwd": "qk_norm_rope_bwd_kernel",
+               "dta_swiglu_fwd": "swiglu_fwd_kernel", "dta_swiglu_bwd": "swiglu_bwd_kernel"}
 
 
 def loss_fn(logprob, entropy, attachment):            # run.py:149-152
@@ -60,9 +71,12 @@ def host_threads() -> int:
     return max(1, min(n, 16))
 
 
+# --------------------------------------------------------------------------------------------------------------
+# CPU baseline (child process; the only place besides tests/ and smoke() that touches oracle/)
+# --------------------------------------------------------------------------------------------------------------
 def cpu_baseline_worker():
-    """The oracle's restatement of the reference push/pop schedule (tree_training_engine.py:555-616) on
-    the host cores, Qwen3-0.6B dims, on a bounded tau2-shaped sample.  Runs in a child process."""
+    """The oracle's restatement of the reference push/pop schedule (tree_training_engine.py:555-616) on the host cores, Qwen3-0.6B
+    dims: BASELINE config 1 and a bounded tau2-shaped sample."""
     import numpy as np
     from oracle import model_oracle as mo
     from oracle import trie_oracle as to
@@ -70,25 +84,36 @@ def cpu_baseline_worker():
     torch.set_num_threads(threads)
     flags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
     dtype = torch.bfloat16 if ("avx512_bf16" in flags or "amx_bf16" in flags) else torch.float32    # reference dtypes: run.py:122-126
-    case = {"kind": "tau2", "seed": 0, "G": 3, "sys_len": 750, "turns": 3, "lo": 75, "hi": 340, "cap": 6144}
-    seqs = [np.asarray(s, dtype=np.int64) for s in synth.make_case(case)]
-    w = {k: v.requires_grad_(True) for k, v in mo.init_weights(mo.QWEN3_0P6B, seed=0, dtype=dtype).items()}
-    t0 = time.time()
-    trie = to.TokenTrieOracle(seqs, [dict(ATTACH) for _ in seqs]); trie.backward_permute()
-    eng = mo.StackEngineOracle(mo.QWEN3_0P6B, w, max(len(s) for s in seqs), dtype=dtype)
-    eng.backward(trie, mo.default_loss, 2048)
-    dt = time.time() - t0
-    st = trie.get_stats("backward", 2048)
     name = "bf16" if dtype == torch.bfloat16 else "fp32 (host has no avx512_bf16/amx)"
+    w = {k: v.requires_grad_(True) for k, v in mo.init_weights(mo.QWEN3_0P6B, seed=0, dtype=dtype).items()}
+
+    def run(seqs):
+        for v in w.values():
+            v.grad = None
+        t0 = time.time()
+        trie = to.TokenTrieOracle(seqs, [dict(ATTACH) for _ in seqs]); trie.backward_permute()
+        eng = mo.StackEngineOracle(mo.QWEN3_0P6B, w, max(len(s) for s in seqs), dtype=dtype)
+        eng.backward(trie, mo.default_loss, 2048)
+        return time.time() - t0, trie.get_stats("backward", 2048)
+
+    seqs1 = [np.asarray(s, dtype=np.int64) for s in synth.config1(0)]
+    run(seqs1)                                                   # warm-up (thread pool, allocator), as run_all.py:88-92
+    dt1, st1 = run(seqs1)
+    case = {"kind": "tau2", "seed": 0, "G": 3, "sys_len": 750, "turns": 3, "lo": 75, "hi": 340, "cap": 6144}
+    seqs2 = [np.asarray(s, dtype=np.int64) for s in synth.make_case(case)]
+    dt2, st2 = run(seqs2)
     print("CPU_BASELINE " + json.dumps({
-        "value": st["n_tokens"] / dt, "unit": "tokens/s", "cores": threads, "kind": "port",
-        "sample": f"tau2-shaped call at 3/8 length scale (G=3, sys 750, 3 turns of 75-340): {st['n_sequences']} seqs, "
-                  f"{st['n_tokens']} tokens, {st['n_tree_tokens']} tree tokens, Qwen3-0.6B {name}, reference push/pop schedule, "
-                  f"block_size 2048, {dt:.1f} s",
-        "tree_tokens_per_s": st["n_tree_tokens"] / dt}), flush=True)
+        "value": st2["n_tokens"] / dt2, "unit": "tokens/s", "cores": threads, "kind": "port",
+        "sample": f"tau2-shaped call at 3/8 length scale (G=3, sys 750, 3 turns of 75-340): {st2['n_sequences']} seqs, {st2['n_tokens']} tokens, "
+                  f"{st2['n_tree_tokens']} tree tokens, Qwen3-0.6B {name}, reference push/pop schedule, block_size 2048, {dt2:.1f} s on {threads} threads; "
+                  "the GPU `value` is measured on the FULL tau2 call (48 seqs, ~180k tokens, ~25.5k tree tokens) — shallower tries favour the CPU",
+        "tree_tokens_per_s": st2["n_tree_tokens"] / dt2,
+        "config1": {"value": st1["n_tokens"] / dt1, "unit": "tokens/s", "seconds": dt1,
+                    "sample": f"BASELINE config 1: 4 rollouts x 256 tokens sharing a 256-token prompt ({st1['n_tokens']} tokens, {st1['n_tree_tokens']} tree tokens), "
+                              f"Qwen3-0.6B {name}, tree backward after one warm-up"}}), flush=True)
 
 
-def cpu_baseline(limit_s: int = 240):
+def cpu_baseline(limit_s: int = 300):
     """Bounded: the child is killed after `limit_s` and the leg reports null instead of stalling the bench."""
     import subprocess
     print(f"[bench] timing the CPU baseline (oracle, host cores) in a child process, limit {limit_s}s ...", file=sys.stderr, flush=True)
@@ -104,18 +129,26 @@ def cpu_baseline(limit_s: int = 240):
         return {"value": None, "unit": "tokens/s", "cores": host_threads(), "kind": "port", "sample": f"worker exceeded {limit_s}s and was stopped"}
 
 
+# --------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--block-size", type=int, default=2048)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--model", default="qwen3-0.6b", choices=["qwen3-0.6b", "qwen3-4b"])
+    ap.add_argument("--workload", default="tau2", choices=["tau2", "wide"])
+    ap.add_argument("--vocab-parallel", action="store_true", help="BASELINE config 4: split the LM-head vocabulary over the ranks (every rank runs the same batch)")
+    ap.add_argument("--engine-mode", default="auto", choices=["auto", "packed", "stack"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg at N > 1")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker()
+    wide = args.workload == "wide"
+    steps = args.steps if args.steps is not None else (2 if wide else 6)
+    warmup = args.warmup if args.warmup is not None else (1 if wide else 2)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -124,95 +157,137 @@ def main():
     local = local % max(n_dev, 1)               # rehearsal on a 1-GPU box: ranks share the card (gloo only, below)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = None
     if world > 1:
         # RCCL ("nccl") needs one GPU per rank; DTA_BENCH_BACKEND=gloo rehearses the N>1 code path on one GPU
         backend = os.environ.get("DTA_BENCH_BACKEND", "nccl")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
+    dtype = torch.float16 if wide else torch.bfloat16                     # BASELINE config 5 is fp16
     cfg = synth.QWEN3_0P6B if args.model == "qwen3-0.6b" else synth.QWEN3_4B
-    model = build_model(cfg, dev, torch.bfloat16)
-    engine = TreeTrainingEngine(make_config(cfg), dev, torch.bfloat16, max_seq_len=16384)     # run_all.py:86
+    model = build_model(cfg, dev, dtype)
+    engine = TreeTrainingEngine(make_config(cfg), dev, dtype, max_seq_len=16384)     # run_all.py:86
+    engine.mode = args.engine_mode
+    tp = args.vocab_parallel and world > 1
+    if tp:
+        engine.tp_group = dist.group.WORLD
     V = cfg["vocab_size"]
+    loss_scale = 1024.0 if wide else 1.0                                   # fp16 at depth 16 384 needs it (tests/test_gpu_engine.py)
+    attach = {k: v * loss_scale for k, v in ATTACH.items()}
 
-    # synthetic global batches, one per step: `world` tau2-shaped calls merged (CPU LongTensors, as the
-    # reference's .pt batches are)
-    total_steps = args.warmup + args.steps
-    batches = []
-    for s in range(total_steps):
-        seqs = []
-        for r in range(world):
-            seqs += synth.as_tensors(synth.tau2(seed=s * world + r, V=V))
-        batches.append(seqs)
+    def call(seed):
+        if wide:
+            return synth.as_tensors(synth.wide(seed=seed + 1, V=V))
+        return synth.as_tensors(synth.tau2(seed=seed, V=V))
 
-    stats_acc = {"n_tokens": 0, "n_tree_tokens": 0, "pairs": 0}
+    # ---- gradient reduction (N > 1, data parallel): persistent flat buffers, every param.grad a view, reduced in place and
+    # overlapped with the backward.  DTA_BENCH_OVERLAP=0 reduces after the backward instead.
+    reducer = None
+    if world > 1 and not tp:
+        reducer = dp.GradReducer(model.parameters(), overlap=os.environ.get("DTA_BENCH_OVERLAP", "1") == "1")
 
-    # The partition is OFFLINE in the reference (data_parallel.py writes {name}_bin{k}.pt ahead of the runs,
-    # exp/exp_dp.py:43-49) and its timed region is trie build + permute + engine call per bin (run.py:90-108):
-    # same here — bins are planned before the clock starts, everything from TokenTrie(...) on is timed.
-    my_seqs = [[seqs[i] for i in dp.my_bin(seqs, rank, world, "backward", args.block_size)] for seqs in batches]
+    def zero():
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            model.zero_grad(set_to_none=True)
 
-    # N > 1: plain post-backward gradient all-reduce (SUM, no averaging) by default; DTA_BENCH_OVERLAP=1 runs it bucket by
-    # bucket under the backward pass (dp.OverlappedGradAllReduce, gloo-tested; opt-in until it has run on RCCL: this
-    # round's GPU boxes have one GPU)
-    overlap = world > 1 and os.environ.get("DTA_BENCH_OVERLAP", "0") == "1"
-    reducer = dp.OverlappedGradAllReduce(model.parameters()) if overlap else None
-
-    def step(mine, timed: bool):
-        model.zero_grad(set_to_none=True)
-        trie = TokenTrie(mine, [dict(ATTACH) for _ in mine])
-        trie.backward_permute()
+    def step(mine, acc=None):
+        """One pass of the hot path over this rank's sequences (possibly none: an empty bin still takes part in the reduce)."""
+        zero()
+        t_begin = time.time()
+        trie = TokenTrie(mine, [dict(attach) for _ in mine], device=dev)
+        if mine:
+            trie.backward_permute()
         if reducer is not None:
             reducer.start()
         loss = engine.backward(model, trie, loss_fn, args.block_size)
+        t_compute = None
+        if acc is not None and acc.get("split_times"):
+            torch.cuda.synchronize(); t_compute = time.time() - t_begin
         if reducer is not None:
             reducer.finish()
-        elif world > 1:
-            dp.allreduce_grads(model.parameters())
-        if timed:
-            st = trie.get_stats("backward", args.block_size)
-            stats_acc["n_tokens"] += st["n_tokens"]; stats_acc["n_tree_tokens"] += st["n_tree_tokens"]
-            stats_acc["pairs"] += st["sum_depth"] + st["n_tree_tokens"]
-        return loss
+        if acc is not None:
+            st = trie.get_stats("backward", args.block_size) if mine else {"n_tokens": 0, "n_tree_tokens": 0, "sum_depth": 0}
+            acc["n_tokens"] += st["n_tokens"]; acc["n_tree_tokens"] += st["n_tree_tokens"]
+            acc["pairs"] += st["sum_depth"] + st["n_tree_tokens"]
+        return loss, t_compute
 
-    for s in range(args.warmup):
-        step(my_seqs[s], False)
-        model.zero_grad(set_to_none=True)
+    def timed(batches, acc):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for b in batches:
+            step(b, acc)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.time() - t0
 
+    def reduce_stats(wall, acc):
+        tot = torch.tensor([wall, float(acc["n_tokens"]), float(acc["n_tree_tokens"]), float(acc["pairs"])], device=dev, dtype=torch.float64)
+        if world > 1:
+            mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            if tp:                                  # every rank ran the same batch: count it once
+                return float(mx[0]), float(mx[1]), float(mx[2]), float(mx[3])
+            return float(mx[0]), float(sm[1]), float(sm[2]), float(sm[3])
+        return float(tot[0]), float(tot[1]), float(tot[2]), float(tot[3])
+
+    new_acc = lambda **kw: dict({"n_tokens": 0, "n_tree_tokens": 0, "pairs": 0}, **kw)
+
+    # ---- WEAK leg (= `value`): one call per rank per step.  The partition is OFFLINE in the reference (data_parallel.py writes
+    # {name}_bin{k}.pt ahead of the runs, exp/exp_dp.py:43-49) and its timed region is trie build + permute + engine call per bin
+    # (run.py:90-108): same here — bins are planned before the clock starts, everything from TokenTrie(...) on is timed.
+    total_steps = warmup + steps
+    weak = []
+    for s in range(total_steps):
+        if tp:
+            seqs = call(s)
+            weak.append(seqs)
+        else:
+            seqs = []
+            for r in range(world):
+                seqs += call(s * world + r)
+            weak.append([seqs[i] for i in dp.my_bin(seqs, rank, world, "backward", args.block_size)])
+    for s in range(warmup):
+        step(weak[s])
+    zero()
+    acc = new_acc()
+    wall = timed(weak[warmup:], acc)
+    wall, n_tokens, n_tree, pairs = reduce_stats(wall, acc)
+    engine_mode = engine.last_mode
+
+    # ---- ROOFLINE leg: the same steps with HIP events on the launch stream around every C-ABI launch
     timer = ops.KernelTimer()
     ops.KernelTimer.active = timer
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for s in range(args.warmup, total_steps):
-        step(my_seqs[s], True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.time() - t0
+    acc_r = new_acc()
+    wall_r = timed(weak[warmup:], acc_r)
     ops.KernelTimer.active = None
-
-    tot = torch.tensor([wall, float(stats_acc["n_tokens"]), float(stats_acc["n_tree_tokens"])], device=dev, dtype=torch.float64)
-    if world > 1:
-        mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        wall, n_tokens, n_tree = float(mx[0]), float(sm[1]), float(sm[2])
-    else:
-        n_tokens, n_tree = float(tot[1]), float(tot[2])
-
-    # roofline of the dominant kernel (dK/dV): algorithmic FLOPs = 4 products x 2·Hq·D per visible pair
     ms = timer.totals_ms()
+    nbytes = timer.totals_bytes()
+    wall_r, _, _, _ = reduce_stats(wall_r, acc_r)
+    pairs_r = acc_r["pairs"]                                  # this rank's pairs: its own kernels' work
     L, Hq, D = cfg["num_hidden_layers"], cfg["num_attention_heads"], cfg["head_dim"]
-    pairs = stats_acc["pairs"]
+
     def tf(coef, key):
-        t, n = ms[key]
-        return (coef * Hq * D * pairs * L) / (t * 1e-3) / 1e12 if t > 0 else 0.0, (t / n if n else 0.0)
+        t, n = ms.get(key, (0.0, 0))
+        return (coef * Hq * D * pairs_r * L) / (t * 1e-3) / 1e12 if t > 0 else 0.0, (t / n if n else 0.0)
     dkv_tf, dkv_ms = tf(8, "bwd_dkv")
     dq_tf, dq_ms = tf(2, "bwd_dq")
     fwd_tf, fwd_ms = tf(4, "fwd")
-    attn_ms_total = ms["fwd"][0] + ms["bwd_dq"][0] + ms["bwd_dkv"][0] + ms["bwd_dkv_finalize"][0]
-    all_tf = (14 * Hq * D * pairs * L) / (attn_ms_total * 1e-3) / 1e12 if attn_ms_total > 0 else 0.0
+    fin = ms.get("bwd_dkv_finalize", (0.0, 0))
+    attn_ms_total = ms["fwd"][0] + ms["bwd_dq"][0] + ms["bwd_dkv"][0] + fin[0]
+    all_tf = (14 * Hq * D * pairs_r * L) / (attn_ms_total * 1e-3) / 1e12 if attn_ms_total > 0 else 0.0
+    hbm_rows = {}
+    for api, kern in HBM_KERNELS.items():
+        t, n = ms.get(api, (0.0, 0))
+        if n:
+            gbs = nbytes[api] / (t * 1e-3) / 1e9
+            hbm_rows[kern] = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                              "avg_launch_ms": t / n, "launches_per_step": n / max(steps, 1), "algorithmic_bytes_per_launch": nbytes[api] / n}
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; take the latest
     # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE result for the same kernel and trie shape (profiles/)
@@ -227,22 +302,60 @@ def main():
     except Exception:
         pass
 
+    # ---- STRONG leg (N > 1, data parallel): the reference's DP protocol on a fixed batch of calls
+    strong = None
+    if world > 1 and not tp and not args.no_strong and not wide:
+        n_calls = max(steps, 1)
+        per_call = []
+        for s in range(n_calls):
+            seqs = call(s % 16)                                                  # the 16-call batch of SURVEY §8d, in order
+            bins = dp.all_bins(seqs, world, "backward", args.block_size)
+            per_call.append(([seqs[i] for i in bins[rank]], sum(int(x.numel()) for x in seqs)))
+        step(per_call[0][0])                                                     # warm-up of the smaller per-rank shapes
+        t_tot, t_cmp, tok = [], [], 0
+        for mine, n_tok in per_call:
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.time()
+            _, tc = step(mine, {"n_tokens": 0, "n_tree_tokens": 0, "pairs": 0, "split_times": True})
+            torch.cuda.synchronize()
+            t_tot.append(time.time() - t0); t_cmp.append(tc); tok += n_tok
+        tt = torch.tensor([t_tot, t_cmp], device=dev, dtype=torch.float64)        # [2, calls]
+        mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        strong = {"value": tok / float(mx[0].sum()), "unit": "tokens/s", "calls": n_calls,
+                  "definition": "sum n_tokens / sum_calls max_rank(time), every call split N ways by LB_by_DFS_and_TM (exp/exp_dp.py:28-49, exp/calc_time.py:24-42); "
+                                "time = trie build + permute + backward + gradient all-reduce",
+                  "balance": float((sm[1] / (world * mx[1])).mean()), "balance_definition": "mean over calls of sum_k t_k / (N * max_k t_k), t_k = rank k's time up to the reduce",
+                  "ms_per_call": float(mx[0].mean()) * 1e3}
+
+    workload = ("BASELINE config 5: wide/deep trie, 64 branches x 16 384 deep over a 1 024-token root (1 048 576 tokens, 984 064 tree tokens per call), "
+                f"{MODEL_NAME[args.model]} random-init fp16, loss scale {loss_scale:g}") if wide else \
+               ("tau2-16k-shaped trie batch (8 rollouts x 6 turns, 2000-token shared prompt, 48 seqs ~180k tokens per call), "
+                f"{MODEL_NAME[args.model]} random-init bf16")
     out = {
-        "metric": f"tree-attn fwd+bwd tokens/sec, {MODEL_NAME[args.model]} tau2-16k tries", "value": n_tokens / wall, "unit": "tokens/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "tau2-16k-shaped trie batch (8 rollouts x 6 turns, 2000-token shared prompt, 48 seqs ~180k tokens "
-                               f"per call), one call per GPU per step, {MODEL_NAME[args.model]} random-init bf16, tree fwd+bwd, block_size {args.block_size}, permute=ours",
-                   "calls_per_step": world, "balancer": "LB_by_DFS_and_TM" if world > 1 else "none",
-                   "grad_allreduce": ("RCCL sum, 256 MB buckets overlapped with backward" if overlap else "RCCL sum after backward") if world > 1 else "none"},
+        "metric": f"tree-attn fwd+bwd tokens/sec, {MODEL_NAME[args.model]} {'wide/deep' if wide else 'tau2-16k'} tries", "value": n_tokens / wall, "unit": "tokens/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": wall / steps * 1e3,
+        "higher_is_better": True, "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "f16" if wide else "bf16", "data": "synthetic",
+        "config": {"workload": workload + f", tree fwd+bwd, block_size {args.block_size}, permute=ours; "
+                               + ("every rank runs the SAME call with the LM-head vocabulary split over the ranks (config 4)" if tp else "one call per GPU per step"),
+                   "calls_per_step": 1 if tp else world, "balancer": "LB_by_DFS_and_TM" if (world > 1 and not tp) else "none",
+                   "engine_mode": engine_mode,
+                   "grad_allreduce": ("none (vocabulary-parallel run: body replicated, head rows owned per rank)" if tp else
+                                      ("RCCL sum in place on persistent flat buckets, overlapped with backward" if reducer.overlap else "RCCL sum in place after backward")) if world > 1 else "none",
+                   "value_is": "the WEAK-scaling leg (per-GPU work fixed); the reference's fixed-batch protocol is `strong_scaling`"},
         "tree_tokens_per_s": n_tree / wall,
-        "roofline": {"bound": "mfma", "kernel": DKV_KERNEL, "achieved": dkv_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": dkv_tf / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dkv_ms,
-                     "flops_per_pair_per_layer": 8 * Hq * D, "pairs_per_step": pairs / max(args.steps, 1),
-                     "other_kernels": {"tree_attn_fwd_kernel": {"achieved": fwd_tf, "avg_launch_ms": fwd_ms, "flops_per_pair_per_layer": 4 * Hq * D},
-                                       "tree_attn_bwd_dq_kernel": {"achieved": dq_tf, "avg_launch_ms": dq_ms, "flops_per_pair_per_layer": 2 * Hq * D},
-                                       "tree_attn_bwd_dkv_finalize_kernel": {"avg_launch_ms": (ms["bwd_dkv_finalize"][0] / ms["bwd_dkv_finalize"][1]) if ms["bwd_dkv_finalize"][1] else 0.0},
-                                       "attention_fwd+bwd_14HqD": {"achieved": all_tf, "ms_per_step": attn_ms_total / max(args.steps, 1)}}},
+        "strong_scaling": strong,
+        "roofline": {"bound": "mfma", "kernel": DKV_KERNEL, "achieved": dkv_tf, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": dkv_tf / PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dkv_ms,
+                     "flops_per_pair_per_layer": 8 * Hq * D, "pairs_per_step": pairs_r / max(steps, 1),
+                     "measured_in": "a repeat of the timed steps with HIP events around every launch (not inside `value`'s timed region)",
+                     "ms_per_step_with_timers": wall_r / steps * 1e3, "timer_overhead_frac": wall_r / wall - 1.0,
+                     "other_kernels": {"tree_attn_fwd_kernel": {"bound": "mfma", "achieved": fwd_tf, "frac": fwd_tf / PEAK_TFLOPS, "avg_launch_ms": fwd_ms, "flops_per_pair_per_layer": 4 * Hq * D},
+                                       "tree_attn_bwd_dq_kernel": {"bound": "mfma", "achieved": dq_tf, "frac": dq_tf / PEAK_TFLOPS, "avg_launch_ms": dq_ms, "flops_per_pair_per_layer": 2 * Hq * D,
+                                                                   "note": "executes 6*Hq*D per pair (S and dP recomputed); see DESIGN.md §4 for why the backward stays two kernels"},
+                                       "tree_attn_bwd_dkv_finalize_kernel": {"avg_launch_ms": (fin[0] / fin[1]) if fin[1] else 0.0},
+                                       "attention_fwd+bwd_14HqD": {"bound": "mfma", "achieved": all_tf, "frac": all_tf / PEAK_TFLOPS, "ms_per_step": attn_ms_total / max(steps, 1)},
+                                       **hbm_rows}},
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -12,12 +12,25 @@ LIB = os.environ.get("DTA_LIB") or os.path.join(HERE, "libdta_mi355x.so")      #
 SOURCES = ["tree_attn.hip", "trie_kernels.hip", "logprob_kernels.hip", "elementwise_kernels.hip"]
 
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17"]
+DEPS = SOURCES + ["dta_common.h"]
+
+
+def _digest() -> str:
+    """sha256 over the sources, the headers and the compile flags: the .so is rebuilt exactly when one of them changed
+    (mtimes do not survive a snapshot copy to the GPU box)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for path in [os.path.join(CSRC, s) for s in DEPS] + [os.path.join(os.path.dirname(HERE), "include", "dta.h")]:
+        if os.path.exists(path):
+            h.update(path[len(os.path.dirname(HERE)):].encode()); h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(LIB + ".sha256"):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(HERE), "include", "dta.h")]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return open(LIB + ".sha256").read().strip() != _digest()
 
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
@@ -25,10 +38,12 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-o", LIB] + srcs
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    with open(LIB + ".sha256", "w") as f:
+        f.write(_digest() + "\n")
     return LIB
 
 

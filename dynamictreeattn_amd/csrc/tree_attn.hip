@@ -382,7 +382,6 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
 template <int DT, int HPB>
 __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_kernel(AttnParams p) {
   using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
-  constexpr int NT = 256 * HPB, CPT = 1024 / NT;
   __shared__ __attribute__((aligned(16))) char smem[QK_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -424,32 +423,8 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
 
   const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
   const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.v_sh;
-  u32x4 kreg[CPT], vreg[CPT]; int sereg = 0;
-  // chunk id = tid + NT*i -> image row id>>4, chunk id&15: the per-lane byte offset inside a 64-row tile is fixed for the
-  // sweep, so a tile's loads are <scalar tile base> + <32-bit lane offset> (no per-lane 64-bit address arithmetic)
-  uint32_t soff_k[CPT], soff_v[CPT];
-#pragma unroll
-  for (int i = 0; i < CPT; ++i) {
-    const int id = tid + NT * i, row = id >> 4, ch = id & 15;
-    soff_k[i] = (uint32_t)((row * p.kv_st + ch * 8) * (int64_t)sizeof(e));
-    soff_v[i] = (uint32_t)((row * p.v_st + ch * 8) * (int64_t)sizeof(e));
-  }
-#define DQ_LOAD(K0, KEND)                                                                                  \
-  { const int k0_ = (K0);                                                                                  \
-    if (k0_ + 64 <= p.Tk) {                                                                                \
-      const char* kb_ = reinterpret_cast<const char*>(kbase) + (int64_t)k0_ * p.kv_st * (int64_t)sizeof(e); \
-      const char* vb_ = reinterpret_cast<const char*>(vbase) + (int64_t)k0_ * p.v_st * (int64_t)sizeof(e);  \
-      _Pragma("unroll") for (int i_ = 0; i_ < CPT; ++i_) {                                                 \
-        uint32_t ok_ = soff_k[i_], ov_ = soff_v[i_];                                                       \
-        asm volatile("" : "+v"(ok_), "+v"(ov_));   /* keeps the 32->64-bit extension next to the load: scalar-base form */ \
-        kreg[i_] = *reinterpret_cast<const u32x4*>(kb_ + ok_);                                             \
-        vreg[i_] = *reinterpret_cast<const u32x4*>(vb_ + ov_); }                                           \
-    } else { DTA_STAGE_LOAD(kreg, vreg, kbase, vbase, p.kv_st, p.v_st, k0_, p.Tk, NT, CPT) }               \
-    if (tid < 64) { const int ki_ = k0_ + tid; sereg = (ki_ < (KEND)) ? (p.subtree_end ? p.subtree_end[ki_] : 0x7fffffff) : 0; } }
-#define DQ_WRITE(B)                                                                                        \
-  { char* base_ = smem + (B) * (2 * TILE_BYTES + SE_BYTES);                                                \
-    DTA_STAGE_WRITE(kreg, vreg, base_, base_ + TILE_BYTES, NT, CPT)                                        \
-    if (tid < 64) reinterpret_cast<int*>(base_ + 2 * TILE_BYTES)[tid] = sereg; }
+  constexpr int NW = 4 * HPB, BUF = 2 * TILE_BYTES + SE_BYTES;
+  DTA_KV_OFFSETS(NW)                      // K/V tiles by LDS-DMA as in the forward (no staging registers, no ds_write)
 
   f32x16 DQ[4];
 #pragma unroll
@@ -460,21 +435,15 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
 
   const float delta_s = delta * p.scale;
   if (any) {
-    int ck0 = it.k0; bool cmask = it.masked();
-    DQ_LOAD(it.k0, it.kend) DQ_WRITE(0)
+    int ck0 = it.k0, ckend = it.kend; bool cmask = it.masked();
+    DTA_KV_DMA(smem, it.k0, NW)
     bool has_next = it.advance();
-    int nk0 = it.k0; bool nmask = has_next ? it.masked() : false;
-    if (has_next) DQ_LOAD(it.k0, it.kend)
-    __syncthreads();
+    DMA_WAIT(); __syncthreads();
     int cur = 0;
     while (true) {
-      bool has_next2 = false;
-      if (has_next) {
-        DQ_WRITE(cur ^ 1)
-        has_next2 = it.advance();
-        if (has_next2) DQ_LOAD(it.k0, it.kend)
-      }
-      const char* Ks = smem + cur * (2 * TILE_BYTES + SE_BYTES); const char* Vs = Ks + TILE_BYTES;
+      int nk0 = 0, nkend = 0; bool nmask = false;
+      if (has_next) { nk0 = it.k0; nkend = it.kend; nmask = it.masked(); DTA_KV_DMA(smem + (cur ^ 1) * BUF, it.k0, NW) }
+      const char* Ks = smem + cur * BUF; const char* Vs = Ks + TILE_BYTES;
       const int* se_s = reinterpret_cast<const int*>(Ks + 2 * TILE_BYTES);
       // one 32-key block at a time keeps S^T/dP^T at 32 live accumulators (2 waves per SIMD need <= 256 registers)
 #pragma unroll
@@ -489,6 +458,7 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
         }
         // dS^T = P ∘ (dP·scale − delta·scale); the interval mask only on tiles of runs flagged partial
         if (cmask) {
+          const int qlim = qidx < ckend ? qidx : ckend - 1;      // keys at or beyond the run end never count
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
             const int kl = 32 * kb + 8 * gq + 4 * h;
@@ -497,7 +467,7 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int g = 4 * gq + j;
-              const bool ok = (ck0 + kl + j <= qidx) && (qidx < sev[j]);
+              const bool ok = (ck0 + kl + j <= qlim) && (qidx < sev[j]);
               const float pv = ok ? fast_exp2(__builtin_fmaf(X[g], c, -lse2)) : 0.f;
               X[g] = pv * __builtin_fmaf(DP[g], p.scale, -delta_s);
             }
@@ -514,14 +484,12 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
           for (int db = 0; db < 4; ++db) DQ[db] = T::mma(tr_frag<v8>(Ks, 32 * kb + 16 * s2, db, lane), db_, DQ[db]);
         }
       }
-      __syncthreads();
+      DMA_WAIT(); __syncthreads();
       if (!has_next) break;
-      cur ^= 1; ck0 = nk0; cmask = nmask;
-      has_next = has_next2; nk0 = it.k0; nmask = has_next2 ? it.masked() : false;
+      cur ^= 1; ck0 = nk0; ckend = nkend; cmask = nmask;
+      has_next = it.advance();
     }
   }
-#undef DQ_LOAD
-#undef DQ_WRITE
   if (qrow < p.Tq) {
     e* dqp = reinterpret_cast<e*>(p.dq) + (int64_t)qrow * p.dq_st + (int64_t)hq * p.dq_sh;
 #pragma unroll

@@ -50,31 +50,43 @@ class _on:
 
 
 class KernelTimer:
-    """Optional live timing of the attention launches with HIP events recorded on the launch stream
-    (bench.py's roofline leg).  Disabled unless `KernelTimer.active` is set to an instance."""
+    """Optional live timing of the C-ABI launches with HIP events recorded on the launch stream (bench.py's roofline leg).
+    Disabled unless `KernelTimer.active` is set to an instance.  `spans[name]` = [(start event, end event, algorithmic bytes)]."""
     active: Optional["KernelTimer"] = None
 
     def __init__(self):
-        self.spans = {"fwd": [], "bwd_dq": [], "bwd_dkv": [], "bwd_dkv_finalize": []}
+        from collections import defaultdict
+        self.spans = defaultdict(list)
+        for k in ("fwd", "bwd_dq", "bwd_dkv", "bwd_dkv_finalize"):
+            self.spans[k]
 
-    def span(self, name):
+    def span(self, name, nbytes: int = 0):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.spans[name].append((a, b))
+        self.spans[name].append((a, b, nbytes))
         return a, b
 
     def totals_ms(self):
         torch.cuda.synchronize()
-        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.spans.items()}
+        return {k: (sum(s[0].elapsed_time(s[1]) for s in v), len(v)) for k, v in self.spans.items()}
+
+    def totals_bytes(self):
+        return {k: sum(s[2] for s in v) for k, v in self.spans.items()}
 
 
 def _require_cuda(*ts):
     _on(*ts)
 
 
-def _launch(name: str, tensors, *args):
-    """One C-ABI call on the device / current stream of `tensors` (see _on); raises on a non-zero status."""
+def _launch(name: str, tensors, *args, nbytes: int = 0):
+    """One C-ABI call on the device / current stream of `tensors` (see _on); raises on a non-zero status.
+    `nbytes`: algorithmic HBM bytes of the launch (one read of every input, one write of every output) for the roofline leg."""
+    tm = KernelTimer.active
     with _on(*tensors) as stream:
+        if tm is not None:
+            a, b = tm.span(name, nbytes); a.record()
         st = getattr(lib(), name)(*args, stream)
+        if tm is not None:
+            b.record()
     check(st, name)
 
 
@@ -284,7 +296,7 @@ def logprob_entropy_fwd_raw(logits, labels, want_entropy=True, temperature=1.0, 
     lp = torch.empty_like(lse) if labels is not None else None
     _launch("dta_logprob_entropy_fwd", (logits, labels, extra_ptr, extra_labels, extra_out),
             ptr(logits), ptr(labels), ptr(extra_ptr), ptr(extra_labels), ptr(lse), ptr(ent), ptr(lp), ptr(extra_out),
-            R, V, logits.stride(0), float(temperature), _DT_LOGITS[logits.dtype])
+            R, V, logits.stride(0), float(temperature), _DT_LOGITS[logits.dtype], nbytes=R * V * logits.element_size())
     return lse, ent, lp
 
 
@@ -294,7 +306,7 @@ def logprob_entropy_bwd_raw(logits, labels, lse, ent, g_lp, g_ent, temperature=1
     out = logits if out is None else out
     _launch("dta_logprob_entropy_bwd", (logits, out, labels, extra_ptr, extra_labels, lse, g_lp, g_extra, g_ent),
             ptr(logits), ptr(out), ptr(labels), ptr(extra_ptr), ptr(extra_labels), ptr(lse), ptr(ent), ptr(g_lp), ptr(g_extra), ptr(g_ent),
-            R, V, logits.stride(0), out.stride(0), float(temperature), _DT_LOGITS[logits.dtype])
+            R, V, logits.stride(0), out.stride(0), float(temperature), _DT_LOGITS[logits.dtype], nbytes=2 * R * V * logits.element_size())
     return out
 
 
@@ -304,7 +316,7 @@ def logprob_entropy_shard_stats_raw(logits, labels_local, temperature=1.0, extra
     stats = torch.empty((R, 4), dtype=torch.float32, device=logits.device)
     _launch("dta_logprob_entropy_shard_stats", (logits, labels_local, extra_ptr, extra_labels, extra_out),
             ptr(logits), ptr(labels_local), ptr(extra_ptr), ptr(extra_labels), ptr(stats), ptr(extra_out),
-            R, V, logits.stride(0), float(temperature), _DT_LOGITS[logits.dtype])
+            R, V, logits.stride(0), float(temperature), _DT_LOGITS[logits.dtype], nbytes=R * V * logits.element_size())
     return stats
 
 
@@ -520,7 +532,8 @@ class _RMSNorm(torch.autograd.Function):
             xo = torch.empty_like(x2)
         else:
             d2, xo = None, None
-        _launch("dta_rmsnorm_fwd", (x2, d2, w), ptr(x2), ptr(d2), ptr(w), ptr(xo), ptr(y), ptr(rstd), R, H, float(eps), _DT[x.dtype])
+        _launch("dta_rmsnorm_fwd", (x2, d2, w), ptr(x2), ptr(d2), ptr(w), ptr(xo), ptr(y), ptr(rstd), R, H, float(eps), _DT[x.dtype],
+                nbytes=R * H * x2.element_size() * (4 if delta is not None else 2))
         xin = xo if xo is not None else x2
         ctx.save_for_backward(xin, w, rstd)
         ctx.has_delta = delta is not None
@@ -534,7 +547,8 @@ class _RMSNorm(torch.autograd.Function):
         gr = g_res.contiguous().view(R, H) if g_res is not None else None
         dx = torch.empty_like(x2)
         part = torch.empty(lib().dta_rmsnorm_bwd_blocks(R), H, dtype=torch.float32, device=x2.device)
-        _launch("dta_rmsnorm_bwd", (x2, w, dy2, gr), ptr(x2), ptr(w), ptr(dy2), ptr(gr), ptr(rstd), ptr(dx), ptr(part), R, H, _DT[x2.dtype])
+        _launch("dta_rmsnorm_bwd", (x2, w, dy2, gr), ptr(x2), ptr(w), ptr(dy2), ptr(gr), ptr(rstd), ptr(dx), ptr(part), R, H, _DT[x2.dtype],
+                nbytes=R * H * x2.element_size() * (4 if gr is not None else 3))
         dx = dx.view(dy.shape)
         return dx, (dx if ctx.has_delta else None), part.sum(0).to(w.dtype), None
 
@@ -558,7 +572,7 @@ class _QKNormRope(torch.autograd.Function):
         y = torch.empty((T, NH, D), dtype=x.dtype, device=x.device)
         rstd = torch.empty(T * NH, dtype=torch.float32, device=x.device) if w is not None else None
         _launch("dta_qk_norm_rope_fwd", (x, w, cos_sin), ptr(x), ptr(w), ptr(cos_sin), ptr(y), ptr(rstd), T, NH, D, x.stride(0), float(eps),
-                _DT[x.dtype])
+                _DT[x.dtype], nbytes=2 * T * NH * D * x.element_size() + T * D * 4)
         ctx.save_for_backward(x, w if w is not None else cos_sin, cos_sin, rstd if rstd is not None else cos_sin)
         ctx.has_w = w is not None
         return y
@@ -574,7 +588,8 @@ class _QKNormRope(torch.autograd.Function):
         if ctx.has_w:
             part = torch.empty(lib().dta_qk_norm_rope_bwd_blocks(T * NH), D, dtype=torch.float32, device=x.device)
         _launch("dta_qk_norm_rope_bwd", (x, cos_sin, dy), ptr(x), ptr(w) if ctx.has_w else None, ptr(cos_sin), ptr(dy), ptr(rstd) if ctx.has_w else None,
-                ptr(dx), ptr(part), T, NH, D, x.stride(0), dy.stride(0), dy.stride(1), dx.stride(0), _DT[x.dtype])
+                ptr(dx), ptr(part), T, NH, D, x.stride(0), dy.stride(0), dy.stride(1), dx.stride(0), _DT[x.dtype],
+                nbytes=(3 if ctx.has_w else 2) * T * NH * D * x.element_size() + T * D * 4)
         return dx, (part.sum(0).to(w.dtype) if ctx.has_w else None), None, None
 
 
@@ -594,7 +609,7 @@ class _QKVPrep(torch.autograd.Function):
             y = torch.empty((T, NH, D), dtype=qkv.dtype, device=qkv.device)
             rstd = torch.empty(T * NH, dtype=torch.float32, device=qkv.device) if w is not None else None
             _launch("dta_qk_norm_rope_fwd", (qkv, w, cos_sin), ptr(x), ptr(w), ptr(cos_sin), ptr(y), ptr(rstd), T, NH, D, qkv.stride(0), float(eps),
-                    _DT[qkv.dtype])
+                    _DT[qkv.dtype], nbytes=2 * T * NH * D * qkv.element_size() + T * D * 4)
             outs.append(y); rstds.append(rstd if rstd is not None else cos_sin)
         ctx.save_for_backward(qkv, wq if wq is not None else cos_sin, wk if wk is not None else cos_sin, cos_sin, rstds[0], rstds[1])
         ctx.has_w = (wq is not None, wk is not None)
@@ -614,7 +629,7 @@ class _QKVPrep(torch.autograd.Function):
             part = torch.empty(lib().dta_qk_norm_rope_bwd_blocks(T * NH), D, dtype=torch.float32, device=qkv.device) if has_w else None
             _launch("dta_qk_norm_rope_bwd", (qkv, cos_sin, dy), ptr(qkv[:, lo:lo + NH]), ptr(w) if has_w else None, ptr(cos_sin), ptr(dy),
                     ptr(rstd) if has_w else None, ptr(d[:, lo:lo + NH]), ptr(part), T, NH, D, qkv.stride(0), dy.stride(0), dy.stride(1), d.stride(0),
-                    _DT[qkv.dtype])
+                    _DT[qkv.dtype], nbytes=(3 if has_w else 2) * T * NH * D * qkv.element_size() + T * D * 4)
             dws.append(part.sum(0).to(w.dtype) if has_w else None)
         d[:, Hq + Hkv:].copy_(dv)
         return d, dws[0], dws[1], None, None, None, None
@@ -655,7 +670,7 @@ class _SwiGLU(torch.autograd.Function):
             C, ld = g.shape[1], g.shape[1]
         rows = g.shape[0]
         y = torch.empty((rows, C), dtype=g.dtype, device=g.device)
-        _launch("dta_swiglu_fwd", (g, u), ptr(g), ptr(u), ptr(y), rows, C, ld, _DT[g.dtype])
+        _launch("dta_swiglu_fwd", (g, u), ptr(g), ptr(u), ptr(y), rows, C, ld, _DT[g.dtype], nbytes=3 * rows * C * g.element_size())
         ctx.save_for_backward(g, u)
         ctx.fused, ctx.ld = gu is not None, ld
         return y
@@ -670,7 +685,8 @@ class _SwiGLU(torch.autograd.Function):
             dg, du, ldg = dgu[:, :C], dgu[:, C:], 2 * C
         else:
             dg, du, ldg = torch.empty_like(g), torch.empty_like(u), C
-        _launch("dta_swiglu_bwd", (g, u, dy), ptr(g), ptr(u), ptr(dy), ptr(dg), ptr(du), rows, C, ctx.ld, ldg, _DT[g.dtype])
+        _launch("dta_swiglu_bwd", (g, u, dy), ptr(g), ptr(u), ptr(dy), ptr(dg), ptr(du), rows, C, ctx.ld, ldg, _DT[g.dtype],
+                nbytes=5 * rows * C * g.element_size())
         return (dgu, None, None) if ctx.fused else (None, dg, du)
 
 

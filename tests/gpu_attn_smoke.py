@@ -37,7 +37,7 @@ run_case(synth.make_case({"kind": "tau2", "seed": 2, "V": 50, "G": 5, "sys_len":
 run_case(synth.make_case({"kind": "wide", "seed": 1, "V": 1000, "root": 100, "branches": 12, "depth": 400}), tag="wide", dtype=torch.float16)
 # stack form vs rect causal
 for (start, B) in [(0, 64), (100, 37), (1000, 256)]:
-    q, k, v, do = synth.attn_inputs(start, B)
+    q, k, v, do = cases.attn_inputs(start, B)
     qd = q[0].transpose(0, 1).contiguous().bfloat16().to(dev).requires_grad_(True)     # [B,Hq,D]
     kd = k[0].transpose(0, 1).contiguous().bfloat16().to(dev).requires_grad_(True)
     vd = v[0].transpose(0, 1).contiguous().bfloat16().to(dev).requires_grad_(True)

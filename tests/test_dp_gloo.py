@@ -27,6 +27,7 @@ def _init(rank, world, port):
 def _dp_worker(rank, world, port, name, q, overlapped=False, one_leaf=False):
     import sys
     sys.path.insert(0, os.path.dirname(__file__)); sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
+    import cases
     import hostmirror
     from dynamictreeattn_amd import dp, ops, synth, token_trie, tree_training_engine
     from dynamictreeattn_amd.model import Qwen3TreeLM
@@ -40,7 +41,7 @@ def _dp_worker(rank, world, port, name, q, overlapped=False, one_leaf=False):
         setattr(ops, k, getattr(hostmirror, fn))
     _orig = token_trie.TokenTrie.__init__
     token_trie.TokenTrie.__init__ = lambda self, *a, **kw: _orig(self, *a, **{**kw, "device": torch.device("cpu")})
-    case = synth.engine_cases()[name]; cfg = synth.TINY_CFGS[case["cfg"]]
+    case = cases.engine_cases()[name]; cfg = cases.TINY_CFGS[case["cfg"]]
     model = Qwen3TreeLM(cfg).load_named(mo.init_weights(cfg, seed=case["wseed"]))
     seqs = synth.as_tensors(synth.make_case(case["data"]))
     att = [{"w_logprobs": -1.0 - 0.01 * i, "w_entropy": 0.1 + 0.003 * i} for i in range(len(seqs))]
@@ -95,6 +96,7 @@ def test_dp_with_an_empty_bin_still_reduces(overlapped):
     gradients on rank 0 equal the single-process gradients of that sequence."""
     import sys, tempfile
     sys.path.insert(0, os.path.dirname(__file__))
+    import cases
     import hostmirror
     from oracle import model_oracle as mo
     ctx = mp.get_context("spawn"); q = tempfile.mkdtemp(); port = _free_port()
@@ -106,7 +108,7 @@ def test_dp_with_an_empty_bin_still_reduces(overlapped):
     assert res[0]["ids"] == [0] and res[1]["ids"] == []
     # reference value: the oracle's dense pass over that one sequence (fp32)
     from dynamictreeattn_amd import synth
-    case = synth.engine_cases()["d128_minitau"]; cfg = synth.TINY_CFGS[case["cfg"]]
+    case = cases.engine_cases()["d128_minitau"]; cfg = cases.TINY_CFGS[case["cfg"]]
     w = {k: v.clone().requires_grad_(True) for k, v in mo.init_weights(cfg, seed=case["wseed"]).items()}
     seq = synth.make_case(case["data"])[0]
     loss = mo.dense_backward(cfg, w, [seq], [{"w_logprobs": -1.0, "w_entropy": 0.1}], mo.default_loss)

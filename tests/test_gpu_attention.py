@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+import cases
+
 import hostmirror
 from dynamictreeattn_amd import ops, packing, synth
 from oracle import trie_oracle as to
@@ -93,7 +95,7 @@ def test_stack_form_vs_rect_causal_oracle(start, B):
     """q_offset = start, no subtree bound: the reference's per-segment attention (tte:171-186).
     K/V are read IN PLACE from a head-major [Hkv, max_len, D] stack through the stride arguments."""
     Hq, Hkv = 4, 2
-    q, k, v, do = synth.attn_inputs(start, B, Hq=Hq, Hkv=Hkv, seed=start + B)
+    q, k, v, do = cases.attn_inputs(start, B, Hq=Hq, Hkv=Hkv, seed=start + B)
     cap = start + B + 19
     kstack = torch.zeros(Hkv, cap, 128, dtype=torch.bfloat16, device=DEV); vstack = torch.zeros_like(kstack)
     kstack[:, :start + B] = k[0].bfloat16().to(DEV); vstack[:, :start + B] = v[0].bfloat16().to(DEV)
@@ -113,7 +115,7 @@ def test_stack_form_vs_rect_causal_oracle(start, B):
 def test_golden_attention_samples_from_transformers_eager():
     gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "attn_cases.pt"), weights_only=True)
     for name, c in gold.items():
-        q, k, v, do = synth.attn_inputs(c["start"], c["B"], Hq=4, Hkv=2)
+        q, k, v, do = cases.attn_inputs(c["start"], c["B"], Hq=4, Hkv=2)
         qd, kd, vd = (x[0].transpose(0, 1).contiguous().bfloat16().to(DEV).requires_grad_(True) for x in (q, k, v))
         o = ops.tree_attention(qd, kd, vd, ops.stack_meta(c["start"]))
         o.backward(do[0].bfloat16().to(DEV))

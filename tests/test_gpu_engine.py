@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+import cases
+
 from dynamictreeattn_amd import dense, synth
 from dynamictreeattn_amd.model import Qwen3TreeLM
 from dynamictreeattn_amd.token_trie import TokenTrie
@@ -29,8 +31,8 @@ def _att(n):
 
 
 def _setup(name, dtype):
-    case = synth.engine_cases()[name]
-    cfg = synth.TINY_CFGS[case["cfg"]]
+    case = cases.engine_cases()[name]
+    cfg = cases.TINY_CFGS[case["cfg"]]
     w = mo.init_weights(cfg, seed=case["wseed"])
     return Qwen3TreeLM.from_named(cfg, w, DEV, dtype), synth.as_tensors(synth.make_case(case["data"]))
 
@@ -150,7 +152,7 @@ def test_hf_attention_interface_plugin_matches_eager():
     transformers = pytest.importorskip("transformers")
     from dynamictreeattn_amd import hf_attention
     name = hf_attention.register()
-    cfg = synth.TINY_CFGS["d128"]
+    cfg = cases.TINY_CFGS["d128"]
     def build(impl):
         c = transformers.Qwen3Config(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
                                      num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=128, tie_word_embeddings=True,
@@ -182,7 +184,7 @@ def test_wide_deep_trie_with_layer_checkpointing(dtype, loss_scale, tol):
     same kernels.  fp16 needs a loss scale: with mean-over-4096 losses the unscaled per-token gradients
     fall under fp16's normal range (measured: unscaled fp16 tree-vs-dense drifts 1e-2 -> 3e-1 from depth
     512 to 4096 while bf16 stays at 6e-3) — a property of the dtype, as in the reference, not of the path."""
-    cfg = synth.TINY_CFGS["d128"]
+    cfg = cases.TINY_CFGS["d128"]
     m = Qwen3TreeLM.from_named(cfg, mo.init_weights(cfg, seed=5), DEV, dtype)
     seqs = synth.as_tensors(synth.wide(seed=1, V=cfg["vocab_size"], root=256, branches=8, depth=4096))
     att = lambda: [{"w_logprobs": -1.0 * loss_scale, "w_entropy": 0.1 * loss_scale} for _ in seqs]

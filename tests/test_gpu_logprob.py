@@ -91,8 +91,8 @@ def test_public_gather_logprobs_on_hip_vs_reference_golden():
         g1 = logits.grad.clone().cpu(); logits.grad = None
         (ent * go_ent).sum().backward()
         g2 = logits.grad.cpu()
-        assert torch.allclose(g1[:, :48], c["grad_lp_head"], atol=2e-6), name
-        assert torch.allclose(g2[:, :48], c["grad_ent_head"], atol=2e-6), name
+        assert torch.allclose(g1[:, :48], c["grad_lp_head"], atol=5e-6, rtol=1e-4), name          # fp32 kernels (v_exp_f32 / v_log_f32) vs torch fp32
+        assert torch.allclose(g2[:, :48], c["grad_ent_head"], atol=5e-6, rtol=1e-4), name
         assert torch.allclose(g1.abs().sum(-1), c["grad_lp_rowsum_abs"], rtol=2e-4), name
         assert torch.allclose(g2.abs().sum(-1), c["grad_ent_rowsum_abs"], rtol=2e-4, atol=1e-5), name
 
@@ -107,12 +107,12 @@ def test_public_functions_shape_quirk_and_grads_vs_oracle(dtype, tol):
     logits = (torch.randn(1, B, V, generator=g) * 2).to(dtype)
     labels = torch.randint(0, V, (1, B - 1), generator=g)
     g1, g2 = torch.randn(1, B - 1, generator=g), torch.randn(1, B, generator=g)
-    x = logits.float().requires_grad_(True)
+    x = logits.float().clone().requires_grad_(True)
     lp_all = torch.log_softmax(x / temp, -1)
     lp_ref = lp_all[:, :B - 1].gather(-1, labels[..., None]).squeeze(-1)
     ent_ref = -(lp_all.exp() * lp_all).sum(-1)
     ((lp_ref * g1).sum() + (ent_ref * g2).sum()).backward()
-    ld = logits.to(DEV).requires_grad_(True)
+    ld = logits.detach().to(DEV).requires_grad_(True)
     lp, ent = vp.gather_logprobs_entropy(ld, labels.to(DEV), temperature=temp)
     assert lp.shape == (1, B - 1) and ent.shape == (1, B)
     assert (lp.detach().cpu() - lp_ref.detach()).abs().max() <= 2e-5 * (1 + lp_ref.abs().max())
@@ -161,7 +161,7 @@ def test_lm_head_rows_vs_plain_torch():
             assert float((x - y).norm() / (y.norm() + 1e-9)) <= tol, (keep, i)
 
 
-def _tp_worker(rank, world, port, outdir):
+def _tp_worker(rank, world, port, outdir, T=300, V=1024, chunk=128):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
@@ -169,18 +169,17 @@ def _tp_worker(rank, world, port, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks share the one GPU of the box: gloo, not RCCL
     from dynamictreeattn_amd import ops as _ops
     g = torch.Generator().manual_seed(0)
-    T, H, V = 300, 64, 1024
+    H = 64
     h = (torch.randn(T, H, generator=g) * 0.5).bfloat16().to(DEV).requires_grad_(True)
     W = (torch.randn(V, H, generator=g) * 0.2).bfloat16().to(DEV)
     nxt = torch.randint(0, V, (T,), generator=g).to(DEV)
-    fork_rows = torch.tensor([3, 3, 250, 299]).to(DEV); fork_tok = torch.tensor([1, V // 2 + 3, 17, V - 1]).to(DEV)
+    fork_rows = torch.tensor([3, 3, 250, T - 1]).to(DEV); fork_tok = torch.tensor([1, V // 2 + 3, 17, V - 1]).to(DEV)
     fork_ptr = torch.searchsorted(fork_rows, torch.arange(T + 1, device=DEV)).to(torch.int32)
     go = [torch.randn(n, generator=g).to(DEV) for n in (T, 4, T)]
     Vp = V // world
     Ws = W[rank * Vp:(rank + 1) * Vp].clone().requires_grad_(True)
     out = {}
     for keep in (1 << 40, 0):
-        chunk = 128
         bounds = np.searchsorted(fork_rows.cpu().numpy(), np.arange(0, T + chunk, chunk)).tolist()
         h.grad = None; Ws.grad = None
         a, b, c = _ops.lm_head_rows(h, Ws, nxt, fork_ptr, fork_tok, fork_rows, bounds, True, chunk, keep, tp_group=dist.group.WORLD, vocab_offset=rank * Vp)
@@ -190,33 +189,36 @@ def _tp_worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_vocab_sharded_lm_head_two_ranks_vs_unsharded(tmp_path):
+@pytest.mark.parametrize("T,V,chunk", [(300, 1024, 128), (2048, 2 * 18992, 1024)])
+def test_vocab_sharded_lm_head_two_ranks_vs_unsharded(tmp_path, T, V, chunk):
     """Config 4's logit split: two gloo ranks (sharing this box's GPU) each hold half of the vocabulary; per-shard
-    HIP statistics + 2 all-reduces must reproduce the unsharded operator (values, dh, and dW on the own slice)."""
+    HIP statistics + 2 all-reduces must reproduce the unsharded operator (values, dh, and dW on the own slice).  The second case
+    has the REAL shard shape of Qwen3 over 8 ranks: [rows, 151 936 / 8 = 18 992] bf16 per rank, 1024-row chunks."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, str(tmp_path), T, V, chunk)) for r in range(2)]
     [p.start() for p in procs]; [p.join(300) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     g = torch.Generator().manual_seed(0)
-    T, H, V = 300, 64, 1024
+    H = 64
     h = (torch.randn(T, H, generator=g) * 0.5).bfloat16().to(DEV).requires_grad_(True)
     W = (torch.randn(V, H, generator=g) * 0.2).bfloat16().to(DEV).requires_grad_(True)
     nxt = torch.randint(0, V, (T,), generator=g).to(DEV)
-    fork_rows = torch.tensor([3, 3, 250, 299]).to(DEV); fork_tok = torch.tensor([1, V // 2 + 3, 17, V - 1]).to(DEV)
+    fork_rows = torch.tensor([3, 3, 250, T - 1]).to(DEV); fork_tok = torch.tensor([1, V // 2 + 3, 17, V - 1]).to(DEV)
     fork_ptr = torch.searchsorted(fork_rows, torch.arange(T + 1, device=DEV)).to(torch.int32)
     go = [torch.randn(n, generator=g).to(DEV) for n in (T, 4, T)]
-    bounds = np.searchsorted(fork_rows.cpu().numpy(), np.arange(0, T + 128, 128)).tolist()
-    a, b, c = ops.lm_head_rows(h, W, nxt, fork_ptr, fork_tok, fork_rows, bounds, True, 128, 1 << 40)
+    bounds = np.searchsorted(fork_rows.cpu().numpy(), np.arange(0, T + chunk, chunk)).tolist()
+    a, b, c = ops.lm_head_rows(h, W, nxt, fork_ptr, fork_tok, fork_rows, bounds, True, chunk, 1 << 40)
     ((a * go[0]).sum() + (b * go[1]).sum() + (c * go[2]).sum()).backward()
     ref = [t.detach().float().cpu() for t in (a, b, c, h.grad)]
+    Vp = V // 2
     for rank in (0, 1):
         res = torch.load(os.path.join(str(tmp_path), f"tp{rank}.pt"), weights_only=True)
         for keep, got in res.items():
             for i in range(3):
                 assert (got[i] - ref[i]).abs().max() <= 2e-3 * (1 + ref[i].abs().max()), (rank, keep, i)
             assert float((got[3] - ref[3]).norm() / ref[3].norm()) <= 1.5e-2
-            dW_ref = W.grad.float().cpu()[rank * 512:(rank + 1) * 512]
+            dW_ref = W.grad.float().cpu()[rank * Vp:(rank + 1) * Vp]
             assert float((got[4] - dW_ref).norm() / dW_ref.norm()) <= 1.5e-2

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+import cases
+
 import hostmirror
 from dynamictreeattn_amd import synth
 from dynamictreeattn_amd.token_trie import TokenTrie, _DeviceTokens, _device_trie_arrays
@@ -85,7 +87,7 @@ def test_full_size_lcp_vs_c_oracle():
 def test_preorder_meta_kernel_vs_host_mirror():
     from dynamictreeattn_amd.tree_training_engine import _PackedTrie
     dev = torch.device("cuda:0")
-    for case in synth.trie_cases()[:14] + synth.trie_cases()[20:30]:
+    for case in cases.trie_cases()[:14] + cases.trie_cases()[20:30]:
         seqs = synth.as_tensors(synth.make_case(case))
         for perm in ("forward_permute", "backward_permute"):
             t = TokenTrie(seqs); getattr(t, perm)()

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+import cases
+
 import hostmirror
 from dynamictreeattn_amd import data_parallel as dp
 from dynamictreeattn_amd import packing, synth
@@ -124,7 +126,7 @@ def test_public_balancer_entries_bit_exact(balancer_golden, monkeypatch):
 
 def test_packing_plan_matches_bruteforce():
     from oracle import trie_oracle as to
-    for case in synth.trie_cases():
+    for case in cases.trie_cases():
         seqs = synth.make_case(case)
         if sum(map(len, seqs)) > 3000:
             continue
@@ -163,7 +165,7 @@ def test_packing_plan_matches_bruteforce():
 
 
 def test_padded_plan_keeps_real_tokens_and_isolates_filler():
-    for case in synth.trie_cases()[:12]:
+    for case in cases.trie_cases()[:12]:
         seqs = synth.make_case(case)
         if sum(map(len, seqs)) > 3000:
             continue
@@ -233,13 +235,13 @@ def _att(n):
 
 def _model(name):
     from dynamictreeattn_amd.model import Qwen3TreeLM
-    case = synth.engine_cases()[name]
-    cfg = synth.TINY_CFGS[case["cfg"]]
+    case = cases.engine_cases()[name]
+    cfg = cases.TINY_CFGS[case["cfg"]]
     m = Qwen3TreeLM(cfg).load_named(mo.init_weights(cfg, seed=case["wseed"]))
     return m, synth.as_tensors(synth.make_case(case["data"]))
 
 
-@pytest.mark.parametrize("name", list(synth.engine_cases()))
+@pytest.mark.parametrize("name", list(cases.engine_cases()))
 def test_engine_forward_fp32_vs_reference(name, eng_gold):
     m, seqs = _model(name); g = eng_gold[name]
     for perm in ("idx", "forward"):
@@ -251,7 +253,7 @@ def test_engine_forward_fp32_vs_reference(name, eng_gold):
             assert a.dtype == torch.float32 and torch.allclose(a, b, atol=3e-5, rtol=0)
 
 
-@pytest.mark.parametrize("name", list(synth.engine_cases()))
+@pytest.mark.parametrize("name", list(cases.engine_cases()))
 @pytest.mark.parametrize("perm", ["ours", "idx", "random"])
 def test_engine_backward_fp32_vs_reference(name, perm, eng_gold):
     m, seqs = _model(name); g = eng_gold[name]
@@ -269,7 +271,7 @@ def test_engine_backward_fp32_vs_reference(name, perm, eng_gold):
         TreeTrainingEngine(m.config, CPU, torch.float32, 3).backward(m, t, mo.default_loss, 2048)
 
 
-@pytest.mark.parametrize("name", list(synth.engine_cases()))
+@pytest.mark.parametrize("name", list(cases.engine_cases()))
 @pytest.mark.parametrize("bs,perm", [(7, "ours"), (64, "ours"), (2048, "ours"), (7, "idx"), (33, "random")])
 def test_blockwise_stack_engine_fp32_vs_reference(name, bs, perm, eng_gold):
     """engine.mode = "stack": the memory-bounded push/pop walk over the KV stack (dynamictreeattn_amd/stack_engine.py — the
@@ -315,7 +317,7 @@ def test_engine_accepts_a_huggingface_module_by_duck_typing(eng_gold):
     """the engine drives an HF Qwen3ForCausalLM through its own nn.Parameters."""
     transformers = pytest.importorskip("transformers")
     name = "d128_minitau"
-    case = synth.engine_cases()[name]; cfg = synth.TINY_CFGS[case["cfg"]]
+    case = cases.engine_cases()[name]; cfg = cases.TINY_CFGS[case["cfg"]]
     c = transformers.Qwen3Config(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
                                  num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
                                  num_key_value_heads=cfg["num_key_value_heads"], head_dim=cfg["head_dim"], tie_word_embeddings=True,

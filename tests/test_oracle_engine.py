@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+import cases
+
 from dynamictreeattn_amd import synth
 from oracle import model_oracle as mo
 from oracle import trie_oracle as to
@@ -20,8 +22,8 @@ def eng_gold():
 
 
 def _setup(name):
-    case = synth.engine_cases()[name]
-    cfg = synth.TINY_CFGS[case["cfg"]]
+    case = cases.engine_cases()[name]
+    cfg = cases.TINY_CFGS[case["cfg"]]
     w = mo.init_weights(cfg, seed=case["wseed"])
     seqs = [np.asarray(s, dtype=np.int64) for s in synth.make_case(case["data"])]
     return cfg, w, seqs
@@ -31,7 +33,7 @@ def _att(n):
     return [{"w_logprobs": -1.0 - 0.01 * i, "w_entropy": 0.1 + 0.003 * i} for i in range(n)]
 
 
-@pytest.mark.parametrize("name", list(synth.engine_cases()))
+@pytest.mark.parametrize("name", list(cases.engine_cases()))
 def test_forward_logprobs(name, eng_gold):
     cfg, w, seqs = _setup(name); g = eng_gold[name]
     for k, v in w.items():        # the RNG that makes the weights has not drifted
@@ -48,7 +50,7 @@ def test_forward_logprobs(name, eng_gold):
         assert torch.allclose(a, b, atol=2e-5, rtol=0)
 
 
-@pytest.mark.parametrize("name", list(synth.engine_cases()))
+@pytest.mark.parametrize("name", list(cases.engine_cases()))
 @pytest.mark.parametrize("tag,bs,cut,perm", [("bs2048", 2048, True, "ours"), ("bs7", 7, True, "ours"),
                                              ("bs7_nocut_idx", 7, False, "idx")])
 def test_backward_grads(name, tag, bs, cut, perm, eng_gold):
@@ -66,7 +68,7 @@ def test_backward_grads(name, tag, bs, cut, perm, eng_gold):
         assert mo.grad_ratio(ref[n], w[n].grad) <= 2e-5 + 2 * slack, (name, tag, n)
 
 
-@pytest.mark.parametrize("name", list(synth.engine_cases()))
+@pytest.mark.parametrize("name", list(cases.engine_cases()))
 def test_dense_backward(name, eng_gold):
     cfg, w, seqs = _setup(name); g = eng_gold[name]
     w = {k: v.clone().requires_grad_(True) for k, v in w.items()}
@@ -103,7 +105,7 @@ def test_attention_operator_vs_transformers_eager():
     from oracle.attn_oracle import rect_causal_attention
     gold = torch.load(os.path.join(GOLD, "attn_cases.pt"), weights_only=True)
     for name, c in gold.items():
-        q, k, v, do = synth.attn_inputs(c["start"], c["B"], Hq=4, Hkv=2)
+        q, k, v, do = cases.attn_inputs(c["start"], c["B"], Hq=4, Hkv=2)
         q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
         o = rect_causal_attention(q[0], k[0], v[0], c["start"])         # [B,Hq,D]
         (o * do[0]).sum().backward()
