@@ -39,8 +39,9 @@ class _DeviceTokens:
         lens = [int(t.numel()) for t in inputs]
         starts = np.zeros(len(lens) + 1, np.int64)
         np.cumsum(lens, out=starts[1:])
+        from ._staging import upload
         flat = torch.cat([t.reshape(-1).to(torch.long) for t in inputs]) if inputs else torch.zeros(0, dtype=torch.long)
-        self.tokens = flat.to(device, non_blocking=True)
+        self.tokens = upload([flat.numpy()], device, np.int64)[0]          # one asynchronous copy out of page-locked staging
         self.starts = starts[:-1].copy()      # per ORIGINAL sequence id
         self.lens = np.asarray(lens, np.int32)
         self.device = device
@@ -54,8 +55,9 @@ def _device_trie_arrays(dev: _DeviceTokens, order: Sequence[int], leafize: bool)
     S = len(order)
     d = dev.device
     idx = np.asarray(order, np.int64)
-    meta = torch.from_numpy(np.concatenate([dev.starts[idx], dev.lens[idx].astype(np.int64)])).to(d)     # one H2D: starts | lens
-    starts, lens = meta[:S], meta[S:].to(torch.int32)
+    from ._staging import upload
+    starts, lens64 = upload([dev.starts[idx], dev.lens[idx]], d, np.int64)                                  # one asynchronous H2D: starts | lens
+    lens = lens64.to(torch.int32)
     n_lcp = max(S - 1, 1)
     buf = torch.zeros(n_lcp + 1 + (3 * S + 1 if leafize else 0), dtype=torch.int32, device=d)
     with torch.cuda.device(d):

@@ -52,27 +52,43 @@ def _get_forkpos(lens, lcp_lens, block_size: Optional[int]) -> list:
 # --------------------------------------------------------------------------------------------------
 # LM head + logprob/entropy over packed rows
 # --------------------------------------------------------------------------------------------------
+def fork_tables_host(fork_child, fork_parent, T: int):
+    """Forks (tokens whose parent is not the preceding packed token) sorted by parent row + their CSR over the T rows."""
+    fork_child, fork_parent = np.asarray(fork_child, np.int64), np.asarray(fork_parent, np.int64)
+    order = np.argsort(fork_parent, kind="stable")
+    fc, fp = fork_child[order], fork_parent[order]
+    ptr = np.zeros(T + 1, np.int64)
+    if fp.size:
+        np.cumsum(np.bincount(fp, minlength=T), out=ptr[1:])
+    return fc, fp, ptr
+
+
 def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tensor, parent: torch.Tensor,
                            want_entropy: bool, chunk: int = 2048, fork_child: Optional[np.ndarray] = None,
-                           fork_parent: Optional[np.ndarray] = None, tp_group=None):
+                           fork_parent: Optional[np.ndarray] = None, tp_group=None, fork_dev=None):
     """lp[t] = log softmax(h[parent[t]] Wᵀ)[tokens[t]] (0 for roots), ent[t] = H(softmax(h[t] Wᵀ)); fp32.
     The arithmetic (vocab_parallel.py:13-27; call sites tte:190-193, 256-261, 361-372) runs in
     `ops.lm_head_rows`: hipBLASLt logits GEMM per row chunk + the HIP statistics kernels; at most one
     [chunk, V] block of fp32-free, model-dtype logits per chunk is ever alive.
-    `fork_child`/`fork_parent`: host lists of the tokens whose parent is not the preceding packed token."""
+    `fork_child`/`fork_parent`: host lists of the tokens whose parent is not the preceding packed token (sorted by parent);
+    `fork_dev` = their device copies (child int64, parent int64, CSR ptr int32 [T+1]) when the caller uploaded them with the
+    plan tables — otherwise they are uploaded here (a blocking copy in the middle of the step)."""
     T = h.shape[0]
     dev = h.device
     if fork_child is None:
         fork_child = np.zeros(0, np.int64); fork_parent = np.zeros(0, np.int64)
-    order = np.argsort(fork_parent, kind="stable")
-    fork_child, fork_parent = np.asarray(fork_child, np.int64)[order], np.asarray(fork_parent, np.int64)[order]
-    fc_dev = torch.from_numpy(fork_child).to(dev)
-    fp_dev = torch.from_numpy(fork_parent).to(dev)
-    ftok = tokens[fc_dev] if fork_child.size else tokens.new_zeros(0)
-    # CSR of the forks over the rows (the HIP kernels pick the fork tokens' log-probs and add their one-hot gradient terms)
-    fork_ptr = torch.searchsorted(fp_dev, torch.arange(T + 1, device=dev)).to(torch.int32) if fork_child.size else None
+    if fork_dev is None:
+        fork_child, fork_parent, ptr = fork_tables_host(fork_child, fork_parent, T)
+        fc_dev, fp_dev = torch.from_numpy(fork_child).to(dev), torch.from_numpy(fork_parent).to(dev)
+        fork_ptr = torch.from_numpy(ptr.astype(np.int32)).to(dev) if fork_child.size else None
+    else:
+        fc_dev, fp_dev, fork_ptr = fork_dev
+    nF = int(np.asarray(fork_child).size)
+    ftok = tokens[fc_dev] if nF else tokens.new_zeros(0)
+    if not nF:
+        fork_ptr = None
     nxt = torch.cat([tokens[1:], tokens.new_zeros(1)])
-    bounds = np.searchsorted(fork_parent, np.arange(0, T + chunk, chunk)).tolist()
+    bounds = np.searchsorted(np.asarray(fork_parent), np.arange(0, T + chunk, chunk)).tolist()
     if tp_group is not None:
         # vocabulary split across the group (BASELINE config 4; vocab_parallel.py:128-130): this rank multiplies by
         # its contiguous slice of the (tied) head weight only; labels stay global
@@ -87,7 +103,7 @@ def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tenso
     chain = torch.zeros(T, dtype=torch.bool, device=dev)           # lp_next[r] = log p(tokens[r+1] | node r)
     chain[1:] = parent[1:] == torch.arange(0, T - 1, device=dev, dtype=parent.dtype)
     lp = torch.cat([lp_next.new_zeros(1), lp_next[:-1]]) * chain
-    if fork_child.size:
+    if nF:
         lp = lp.index_copy(0, fc_dev, lp_fork)
     return lp, ent
 
@@ -118,43 +134,37 @@ class _PackedTrie:
         M, T = plan.M, plan.T
         run_ptr, runs = packing.plan_qtile_runs(plan)
         leaf_off = np.asarray(leaf_off, np.int64)
-        parts = [plan.seg_off, plan.seg_depth0, plan.parent_of_seg, plan.brk_ptr, plan.brk_depth, plan.brk_end,
-                 run_ptr, runs.reshape(-1)]
-        sizes = [p.size for p in parts]
-        pad = [(-s) % 4 for s in sizes]                      # keep every slice 16-byte aligned
-        flat = np.concatenate([np.concatenate([p.astype(np.int32, copy=False), np.zeros(z, np.int32)]) for p, z in zip(parts, pad)])
-        buf = torch.from_numpy(flat).to(device, non_blocking=True)
-        views, o = [], 0
-        for s, z in zip(sizes, pad):
-            views.append(buf[o:o + s]); o += s + z
-        seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, run_ptr_d, runs_d = views
-        leaf_off_d = torch.from_numpy(leaf_off).to(device, non_blocking=True)
-        self.tokens = torch.empty(T, dtype=torch.long, device=device)
-        meta_i = torch.empty(3, T, dtype=torch.int32, device=device)
-        self.depth, self.parent, self.subtree_end = meta_i[0], meta_i[1], meta_i[2]
-        self._expand(trie._dev.tokens, leaf_off_d, seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, M, T)
         # key-tile query ends and the balanced dK/dV work units come from the host plan: no device->host read
         kq = packing.ktile_qend_host(plan)
         units, splits, n_slabs = packing.plan_dkv_units(kq, T, T, 0, n_kv_heads)
-        tail = torch.from_numpy(np.concatenate([kq, units.reshape(-1), splits.reshape(-1)]).astype(np.int32, copy=False)).to(device, non_blocking=True)
-        nk, nu = kq.size, units.size
-        self.meta = ops.TreeAttnMeta(T=T, subtree_end=self.subtree_end, run_ptr=run_ptr_d, runs=runs_d.view(-1, 4), ktile_qend=tail[:nk],
-                                     dkv_units=tail[nk:nk + nu].view(-1, 4), dkv_splits=tail[nk + nu:].view(-1, 4) if splits.shape[0] else None,
-                                     n_slabs=n_slabs)
         first = plan.seg_off[:-1].astype(np.int64)
         nonempty = np.diff(plan.seg_off) > 0
         par = plan.parent_of_seg.astype(np.int64)
         is_fork = nonempty & (par >= 0) & (par != first - 1)
-        self.fork_child, self.fork_parent = first[is_fork], par[is_fork]
+        self.fork_child, self.fork_parent, fork_ptr = fork_tables_host(first[is_fork], par[is_fork], T)
         # root path of every leaf as packed indices (depth 0 .. len-1)
         paths = []
         for i in range(M_real):
             pieces = [np.arange(b, e, dtype=np.int64) for b, e in plan.path_runs[i]]
             pieces.append(np.arange(plan.seg_off[i], plan.seg_off[i + 1], dtype=np.int64))
             paths.append(np.concatenate(pieces))
-        self.path_cat = torch.from_numpy(np.concatenate(paths) if paths else np.zeros(0, np.int64)).to(device, non_blocking=True)
         self.path_sizes = [p.size for p in paths]
+        # ALL tables of the step in two asynchronous uploads out of page-locked staging (one int32, one int64 buffer)
+        from ._staging import upload
+        (seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, run_ptr_d, runs_d, kq_d, units_d, splits_d, fptr_d) = upload(
+            [plan.seg_off, plan.seg_depth0, plan.parent_of_seg, plan.brk_ptr, plan.brk_depth, plan.brk_end, run_ptr, runs.reshape(-1),
+             kq, units.reshape(-1), splits.reshape(-1), fork_ptr], device, np.int32)
+        leaf_off_d, self.path_cat, fc_d, fp_d = upload(
+            [leaf_off, np.concatenate(paths) if paths else np.zeros(0, np.int64), self.fork_child, self.fork_parent], device, np.int64)
+        self.fork_dev = (fc_d, fp_d, fptr_d)
         self.paths = list(torch.split(self.path_cat, self.path_sizes))
+        self.tokens = torch.empty(T, dtype=torch.long, device=device)
+        meta_i = torch.empty(3, T, dtype=torch.int32, device=device)
+        self.depth, self.parent, self.subtree_end = meta_i[0], meta_i[1], meta_i[2]
+        self._expand(trie._dev.tokens, leaf_off_d, seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, M, T)
+        self.meta = ops.TreeAttnMeta(T=T, subtree_end=self.subtree_end, run_ptr=run_ptr_d, runs=runs_d.view(-1, 4), ktile_qend=kq_d,
+                                     dkv_units=units_d.view(-1, 4), dkv_splits=splits_d.view(-1, 4) if splits.shape[0] else None,
+                                     n_slabs=n_slabs)
 
     def _expand(self, tokens, leaf_off, seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, M, T):
         from ._lib import check, lib, ptr
@@ -294,7 +304,7 @@ class TreeTrainingEngine:
         packed = self._pack(token_trie)
         h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, False)
         lp, _ = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, False, self.head_chunk,
-                                       packed.fork_child, packed.fork_parent, self.tp_group)
+                                       packed.fork_child, packed.fork_parent, self.tp_group, packed.fork_dev)
         for i, attach_list in enumerate(token_trie.attach_lists):
             lp_path = lp[packed.paths[i][1:]]
             for attachment, length in attach_list:
@@ -322,7 +332,7 @@ class TreeTrainingEngine:
         self.last_mode = "packed+recompute" if ckpt else "packed"
         h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, ckpt, self._attn_keep_bytes() if ckpt else 0)
         lp, ent = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, True, max(chunk, 1),
-                                         packed.fork_child, packed.fork_parent, self.tp_group)
+                                         packed.fork_child, packed.fork_parent, self.tp_group, packed.fork_dev)
         total = self._path_losses(packed, token_trie, lp, ent, loss_fn)
         if total is None:
             return 0.0
