@@ -259,6 +259,7 @@ def main():
     wall = timed(weak[warmup:], acc)
     wall, n_tokens, n_tree, pairs = reduce_stats(wall, acc)
     engine_mode = engine.last_mode
+    peak_hbm = torch.cuda.max_memory_allocated(dev)
 
     # ---- ROOFLINE leg: the same steps with HIP events on the launch stream around every C-ABI launch
     timer = ops.KernelTimer()
@@ -343,7 +344,7 @@ def main():
                    "grad_allreduce": ("none (vocabulary-parallel run: body replicated, head rows owned per rank)" if tp else
                                       ("RCCL sum in place on persistent flat buckets, overlapped with backward" if reducer.overlap else "RCCL sum in place after backward")) if world > 1 else "none",
                    "value_is": "the WEAK-scaling leg (per-GPU work fixed); the reference's fixed-batch protocol is `strong_scaling`"},
-        "tree_tokens_per_s": n_tree / wall,
+        "tree_tokens_per_s": n_tree / wall, "peak_hbm_gb": peak_hbm / 1e9,
         "strong_scaling": strong,
         "roofline": {"bound": "mfma", "kernel": DKV_KERNEL, "achieved": dkv_tf, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": dkv_tf / PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dkv_ms,

@@ -27,13 +27,19 @@ def upload(arrays: Sequence[np.ndarray], device, dtype=np.int32) -> List[torch.T
         flat = np.zeros(total, dt)
         host = torch.from_numpy(flat)
     else:
-        ring = _ARENAS.setdefault((device.index, dt.str), {"slots": [None] * _RING, "next": 0})
+        ring = _ARENAS.get((device.index, dt.str))
+        if ring is None or ring["cap"] < total:
+            # (re)allocate ALL slots at once, twice the largest request seen: page-locking is slow and synchronises, so it must
+            # happen in the first step of a workload, not whenever a big table lands on a slot that has only held small ones
+            if ring is not None:
+                for ar_ in ring["slots"]:
+                    if ar_["ev"] is not None:
+                        ar_["ev"].synchronize()
+            cap = max(2 * total, 1 << 16)
+            ring = {"cap": cap, "next": 0, "slots": [{"buf": torch.empty(cap, dtype=tdt).pin_memory(), "ev": None} for _ in range(_RING)]}
+            _ARENAS[(device.index, dt.str)] = ring
         i = ring["next"]; ring["next"] = (i + 1) % _RING           # a ring: consecutive uploads of one step never wait for each other
         ar = ring["slots"][i]
-        if ar is None or ar["buf"].numel() < total:
-            cap = max(total, 1 << 16, 2 * (ar["buf"].numel() if ar else 0))
-            ar = {"buf": torch.empty(cap, dtype=tdt).pin_memory(), "ev": None}
-            ring["slots"][i] = ar
         if ar["ev"] is not None:
             ar["ev"].synchronize()                 # the upload issued _RING uploads ago out of this buffer has left the host
         host = ar["buf"][:total]

@@ -69,6 +69,15 @@ def allreduce_grads(params, group=None, bucket_bytes: int = 1 << 29) -> None:
                 p.grad.copy_(g)
 
 
+_ACTIVE: set = set()          # reducers between start() and finish()
+
+
+def defer_active_reducers() -> None:
+    """Called by the block-wise engine before its first backward: see GradReducer.defer."""
+    for r in list(_ACTIVE):
+        r.defer()
+
+
 class GradReducer:
     """The ONE logical all-reduce(SUM) of the step, IN PLACE and overlapped with the backward pass (SURVEY §8e:
     "bucketed and overlapped").
@@ -97,6 +106,7 @@ class GradReducer:
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for p in b] if overlap else []
         self._active = False
+        self._deferred = False
         self._works: list = []
         self.zero_grad()
 
@@ -106,7 +116,14 @@ class GradReducer:
         for p, v in self._views:
             p.grad = v
 
+    def defer(self) -> None:
+        """Stop launching from the hooks for the rest of this step (everything goes out in `finish()`): the block-wise engine
+        accumulates into every parameter once per BLOCK, so "this parameter's gradient arrived" no longer means "final"."""
+        self._deferred = True
+
     def start(self) -> None:
+        self._deferred = False
+        _ACTIVE.add(self)
         for p, v in self._views:           # a `zero_grad(set_to_none=True)` or an optimizer may have replaced the views
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 if p.grad is not None:
@@ -118,7 +135,7 @@ class GradReducer:
         self._active = True
 
     def _on_grad(self, p) -> None:
-        if not self._active:
+        if not self._active or self._deferred:
             return
         self._left[self._bucket_of[id(p)]] -= 1
         while self._next < len(self.buckets) and self._left[self._next] <= 0:
@@ -131,6 +148,7 @@ class GradReducer:
         if not self._active:
             self.start()
         self._active = False
+        _ACTIVE.discard(self)
         while self._next < len(self.buckets):
             self._launch(self._next); self._next += 1
         for w in self._works:

@@ -262,7 +262,9 @@ class TreeTrainingEngine:
         return int(max(bs, min(rows, 16384)))
 
     def _backward_stack(self, model, token_trie, loss_fn, block_rows: int) -> float:
+        from . import dp
         from .stack_engine import StackWalk
+        dp.defer_active_reducers()          # parameters accumulate once per block here: reduce after the walk, not from the hooks
         walk = StackWalk(model, token_trie, self.device, self.dtype, block_rows, self.head_chunk, self.tp_group)
         total = walk.run(loss_fn)
         self.last_mode = f"stack[{block_rows}]x{walk.n_blocks}"
