@@ -6,6 +6,7 @@ any number of arrays into ONE reusable page-locked staging buffer per device and
 returned tensors are views of one device buffer, each 16-byte aligned."""
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Sequence
 
 import numpy as np
@@ -23,7 +24,8 @@ def upload(arrays: Sequence[np.ndarray], device, dtype=np.int32) -> List[torch.T
     pads = [(-s) % per16 for s in sizes]
     total = sum(sizes) + sum(pads)
     tdt = torch.from_numpy(np.zeros(0, dt)).dtype
-    if device.type != "cuda":
+    pageable = device.type != "cuda" or os.environ.get("DTA_STAGING") == "pageable"      # env: diagnostic A/B switch (blocking copies, as round 1)
+    if pageable:
         flat = np.zeros(total, dt)
         host = torch.from_numpy(flat)
     else:
@@ -50,8 +52,8 @@ def upload(arrays: Sequence[np.ndarray], device, dtype=np.int32) -> List[torch.T
         if z:
             flat[o + s:o + s + z] = 0
         o += s + z
-    if device.type != "cuda":
-        dev = host
+    if pageable:
+        dev = host if device.type != "cuda" else host.to(device)
     else:
         with torch.cuda.device(device):
             dev = host.to(device, non_blocking=True)

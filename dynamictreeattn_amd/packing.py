@@ -10,7 +10,6 @@ This module only produces O(M·height) integer tables on the host; the per-token
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from typing import List, Sequence, Tuple
 
@@ -216,13 +215,7 @@ def plan_dkv_units(ktile_qend: np.ndarray, Tk: int, Tq: int, q_offset: int = 0, 
     is_split = nsplit[kt_of] > 1
     slab = np.where(is_split, np.cumsum(is_split) - 1, -1)
     units = np.stack([kt_of, ub, np.maximum(ue, ub), slab], axis=1)
-    # heaviest first (short tail); among units of equal length — the chunks of the root-side key tiles, which carry most of the
-    # traffic — those that sweep the SAME query range are adjacent, so the workgroups resident together on an XCD (one kv head
-    # each: blockIdx % Hkv) read the same Q/dO tiles at about the same time and share them through that XCD's L2
-    if os.environ.get("DTA_UNIT_ORDER", "qrange") == "len":           # diagnostic A/B switch: round-1 order
-        order = np.argsort(-(units[:, 2] - units[:, 1]), kind="stable")
-    else:
-        order = np.lexsort((units[:, 0], units[:, 1], -(units[:, 2] - units[:, 1])))
+    order = np.argsort(-(units[:, 2] - units[:, 1]), kind="stable")       # heaviest first: short tail
     split_kt = np.flatnonzero(nsplit > 1)
     first_slab = (np.cumsum(np.where(nsplit > 1, nsplit, 0)) - np.where(nsplit > 1, nsplit, 0))[split_kt]
     splits = np.stack([split_kt, first_slab, nsplit[split_kt], np.zeros_like(split_kt)], axis=1) if split_kt.size else np.zeros((0, 4), np.int64)

@@ -271,6 +271,37 @@ class TreeTrainingEngine:
         self.cur_len = 0
         return float(total.item()) if total is not None else 0.0
 
+    @staticmethod
+    def packed_rows(n_tree_tokens: int) -> int:
+        """Rows of the packed pass for a trie of `n_tree_tokens` (rounded up to the filler granularity, _PackedTrie)."""
+        T = int(n_tree_tokens)
+        if T >= _PackedTrie.PAD_FROM and T % _PackedTrie.PAD_TO:
+            T += (-T) % _PackedTrie.PAD_TO
+        return T
+
+    def warm_gemm_shapes(self, model, row_counts) -> None:
+        """Library warm-up, not a step: run the projection GEMMs of ONE decoder layer and the LM-head GEMMs (forward, dgrad, wgrad)
+        once per distinct packed row count, on dummy rows and with the attention replaced by the identity.  hipBLASLt picks a
+        solution per exact shape and loads its code object on first use — a one-off cost of up to ≈0.2 s per new row count when the
+        files are cold (measured: one 452 ms step among 230 ms ones in a fresh process) that a training run amortises to nothing
+        and a 6-step benchmark does not."""
+        from types import SimpleNamespace
+        body = model.model
+        one = SimpleNamespace(config=model.config, model=SimpleNamespace(embed_tokens=body.embed_tokens, layers=[body.layers[0]], norm=body.norm))
+        ident = lambda l: (lambda q, k, v: q)
+        for T in sorted({int(t) for t in row_counts if t > 0}):
+            tokens = torch.zeros(T, dtype=torch.long, device=self.device)
+            depth = torch.arange(T, device=self.device, dtype=torch.int32) % 64
+            parent = torch.arange(-1, T - 1, device=self.device, dtype=torch.int32)
+            with torch.enable_grad():
+                h = packed_hidden_states(one, tokens, depth, None, False, 0, ident)
+                lp, ent = packed_logprob_entropy(h, head_weight(model), tokens, parent, True, self.head_chunk)
+                (lp.sum() + ent.sum()).backward()
+        for p in model.parameters():
+            p.grad = None
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
     def _attn_keep_bytes(self) -> int:
         """HBM budget for attention outputs kept across the per-layer recomputation (model.py:_LayerRecompute): a quarter
         of what is free when the pass starts, so the recomputation skips the forward attention kernel on as many layers

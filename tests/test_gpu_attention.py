@@ -153,3 +153,43 @@ def test_full_size_properties_tau2():
     idx_d = torch.from_numpy(idx).to(DEV)
     od, _, _, _ = ops.attn_fwd_raw(q[idx_d].contiguous(), k[idx_d].contiguous(), v[idx_d].contiguous(), ops.stack_meta(0), 128 ** -0.5)
     assert _rel(o[idx_d], od.float().cpu()) < 4e-3
+
+
+def test_full_size_config5_trie_attention_properties():
+    """BASELINE config 5 at FULL size (64 branches x 16 384 deep over a 1 024-token root: 984 064 packed tree tokens, 8.56e9 visible pairs per
+    head, fp16) through the packed tree-attention kernels, checked by size-independent properties against the fp32 oracle:
+    the rows of ONE leaf's root path must equal plain causal attention over that leaf's 16 384 tokens (forward output, dQ; and dK/dV on
+    the leaf's own tail, whose only queries are its own), for the first and the last leaf in DFS order."""
+    from dynamictreeattn_amd.token_trie import TokenTrie
+    from dynamictreeattn_amd.tree_training_engine import _PackedTrie
+    from dynamictreeattn_amd import synth
+    from oracle import attn_oracle
+    Hq, Hkv, D, dtype = 2, 1, 128, torch.float16
+    seqs = synth.as_tensors(synth.wide(seed=1))
+    t = TokenTrie(seqs); t.backward_permute()
+    st = t.get_stats("backward", 2048)
+    assert (st["n_tokens"], st["n_tree_tokens"], st["sum_depth"]) == (1048576, 984064, 8556412416)          # SURVEY §8d
+    pk = _PackedTrie(t, torch.device(DEV), Hkv)
+    T = pk.plan.T
+    g = torch.Generator(device=DEV).manual_seed(5)
+    q, do = (torch.randn(T, Hq, D, generator=g, device=DEV).to(dtype) for _ in range(2))
+    k, v = (torch.randn(T, Hkv, D, generator=g, device=DEV).to(dtype) for _ in range(2))
+    out, lse, _, _ = ops.attn_fwd_raw(q, k, v, pk.meta, D ** -0.5)
+    dq, dk, dv = ops.attn_bwd_raw(q, k, v, out, do, lse, pk.meta, D ** -0.5)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all() and torch.isfinite(dq.float()).all() and torch.isfinite(dk.float()).all()
+    for leaf in (0, len(t.lens) - 1):
+        path = pk.paths[leaf]
+        assert path.numel() == 16384
+        M = len(t.lens)
+        excl = max(t.lcp_lens[leaf - 1] if leaf > 0 else 0, t.lcp_lens[leaf] if leaf < M - 1 else 0)     # depths >= excl belong to this leaf alone
+        assert excl == 1024
+        qs, ks, vs, dos = (x[path].float().cpu().transpose(0, 1).contiguous().requires_grad_(r) for x, r in ((q, True), (k, True), (v, True), (do, False)))
+        ref = attn_oracle.rect_causal_attention(qs, ks, vs, 0)      # [B, Hq, D] fp32
+        ref.backward(dos.transpose(0, 1))
+        rel = lambda a, b: float((a.float().cpu() - b).norm() / b.norm())
+        assert rel(out[path], ref.detach()) <= 2e-3, leaf
+        assert rel(dq[path], qs.grad.transpose(0, 1)) <= 4e-3, leaf
+        # the part of a leaf below every fork is seen by that leaf's queries only: its dK/dV equal the dense ones
+        assert rel(dk[path[excl:]], ks.grad.transpose(0, 1)[excl:]) <= 4e-3, leaf
+        assert rel(dv[path[excl:]], vs.grad.transpose(0, 1)[excl:]) <= 4e-3, leaf

@@ -31,7 +31,8 @@ def _pair(fn_gpu, fn_ref, inputs, dtype):
             assert _rel(a.grad, b.grad) <= (1e-2 if a.dim() == 1 else tol), a.shape
 
 
-@pytest.mark.parametrize("R,H,dtype", [(1, 8, torch.bfloat16), (37, 64, torch.bfloat16), (1000, 1024, torch.bfloat16), (515, 2560, torch.float16), (9, 4096, torch.bfloat16)])
+@pytest.mark.parametrize("R,H,dtype", [(1, 8, torch.bfloat16), (37, 64, torch.bfloat16), (1000, 1024, torch.bfloat16), (515, 2560, torch.float16), (9, 4096, torch.bfloat16),
+                                       (301, 5120, torch.bfloat16), (17, 8192, torch.float16)])      # 5120 = Qwen3-14B / 32B hidden (exp/exp_dp.py:9)
 def test_rmsnorm(R, H, dtype):
     g = torch.Generator().manual_seed(R + H)
     x = torch.randn(R, H, generator=g) * 2; w = (1 + 0.2 * torch.randn(H, generator=g)).to(dtype)
@@ -79,3 +80,22 @@ def test_swiglu(shape, dtype):
     a, b = torch.randn(*shape, generator=g) * 2, torch.randn(*shape, generator=g)
     _pair(ops.swiglu, hostmirror._cpu_swiglu, [a, b], dtype)
     _pair(ops.swiglu_fused, hostmirror._cpu_swiglu_fused, [torch.cat([a, b], dim=-1)], dtype)
+
+
+def test_pending_hip_error_is_reported_not_swallowed():
+    """A HIP error left pending by an earlier runtime call must not be cleared silently by the next launch (round 1 did) nor be
+    blamed on it: the entry point returns DTA_EPRIOR without launching, `check` names the error and clears it, the next call works."""
+    import ctypes
+    from dynamictreeattn_amd import _lib
+    rts = _lib._hip_runtimes_mapped()
+    assert len(rts) == 1, rts                                     # ONE HIP runtime in the process (torch's)
+    hip = ctypes.CDLL(rts[0])
+    g = torch.randn(4, 64, device=DEV, dtype=torch.bfloat16)
+    ops.swiglu(g, g)                                              # library loaded, everything healthy
+    torch.cuda.synchronize()
+    assert hip.hipSetDevice(4096) != 0                            # an unchecked failing runtime call: leaves hipErrorInvalidDevice pending
+    with pytest.raises(RuntimeError, match="already pending"):
+        ops.swiglu(g, g)
+    y = ops.swiglu(g, g)                                          # the report cleared it
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
