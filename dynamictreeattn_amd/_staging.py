@@ -42,8 +42,8 @@ def upload(arrays: Sequence[np.ndarray], device, dtype=np.int32) -> List[torch.T
             _ARENAS[(device.index, dt.str)] = ring
         i = ring["next"]; ring["next"] = (i + 1) % _RING           # a ring: consecutive uploads of one step never wait for each other
         ar = ring["slots"][i]
-        if ar["ev"] is not None:
-            ar["ev"].synchronize()                 # the upload issued _RING uploads ago out of this buffer has left the host
+        if ar["ev"] is not None and not ar["ev"].query():
+            ar["ev"].synchronize()                 # the upload issued _RING uploads ago out of this buffer has not left the host yet (never in practice)
         host = ar["buf"][:total]
         flat = host.numpy()
     o = 0

@@ -47,4 +47,26 @@ if hs and hb:
     out["launches_per_step"] = sum(v for k, v in rows.items() if "Launch" in k) / n_steps
     out["note"] = (f"{n_steps} steps in the run (warm-up {hb['warmup']} + timed {hb['steps']} + roofline leg {hb['steps']}); the bench itself "
                    "synchronises twice per leg around the timed region; hipMemcpyAsync counts every H2D table upload and the D2H reads")
+ht = first("hip/**/*hip_api_trace.csv")
+if ht:
+    # steady-state host synchronisation per step: a step ends with the engine's loss.item() — the one long blocking copy
+    BLOCK = ("hipMemcpyWithStream", "hipStreamSynchronize", "hipDeviceSynchronize", "hipEventSynchronize", "hipMemcpy")
+    ev = []
+    for r in csv.DictReader(open(ht)):
+        fn = r["Function"]
+        if fn in BLOCK or "Launch" in fn:
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), fn))
+    ends = [i for i, (a, b, fn) in enumerate(ev) if fn == "hipMemcpyWithStream" and b - a > 20e6]
+    steps = []
+    for a, b in zip(ends[:-1], ends[1:]):
+        seg = ev[a + 1:b + 1]
+        n_launch = sum(1 for x in seg if "Launch" in x[2])
+        if n_launch < 1000 or n_launch > 2200:
+            continue                                     # leg boundary / first step of the process
+        blk = [x for x in seg if x[2] in BLOCK]
+        steps.append({"launches": n_launch, "blocking_calls": {k: sum(1 for x in blk if x[2] == k) for k in sorted({x[2] for x in blk})},
+                      "host_blocked_ms": round(sum(x[1] - x[0] for x in blk) / 1e6, 2), "step_ms": round((ev[b][1] - ev[a][1]) / 1e6, 2)})
+    out["steady_state_steps_from_hip_trace"] = steps
+    out["steady_state_note"] = ("per step: hipMemcpyWithStream = device->host reads that wait for queued GPU work (the TokenTrie LCP/leaf table and the final "
+                                "loss.item()); everything else in a step is asynchronous launches and copies")
 print(json.dumps(out, indent=1))
