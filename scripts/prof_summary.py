@@ -31,11 +31,35 @@ if ks and b:
     n_steps = b["warmup"] + 2 * b["steps"]                      # warm-up + timed leg + roofline leg
     out["bench_under_kernel_trace"] = {"value": b["value"], "ms_per_step": b["ms_per_step"], "roofline_frac": b["roofline"]["frac"],
                                        "dkv_avg_launch_ms_by_events": b["roofline"]["avg_launch_ms"]}
-    out["kernel_time_ms_per_step"] = total_ns / 1e6 / n_steps
-    out["gpu_busy_frac_of_step"] = out["kernel_time_ms_per_step"] / b["ms_per_step"]
+    out["kernel_time_ms_per_step_incl_setup"] = total_ns / 1e6 / n_steps
     short = lambda n: (n.split("(anonymous namespace)::")[1].split("(")[0] if "(anonymous namespace)::" in n else n.split("(")[0])[:90]
     out["top_kernels"] = [{"kernel": short(r["Name"]), "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                            "ms_per_step": float(r["TotalDurationNs"]) / 1e6 / n_steps, "pct": float(r["Percentage"])} for r in rows[:14]]
+kt = first("trace/**/*kernel_trace.csv")
+if kt:
+    # GPU timeline per step: a step starts at its TokenTrie's lcp_adjacent_kernel; busy = union of the kernel intervals up to the next one
+    recs = []
+    for r in csv.DictReader(open(kt)):
+        recs.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    recs.sort()
+    marks = [i for i, x in enumerate(recs) if "lcp_adjacent_kernel" in x[2]]
+    steps = []
+    for a, b in zip(marks[:-1], marks[1:]):
+        seg = recs[a:b]
+        if sum(1 for x in seg if "tree_attn_bwd_dkv2_kernel" in x[2]) < 2:
+            continue                                     # a statistics-only TokenTrie (bench set-up), not a step
+        span = recs[b][0] - recs[a][0]
+        busy, cur_end = 0, seg[0][0]
+        for s0, e0, _ in seg:
+            if e0 > cur_end:
+                busy += e0 - max(s0, cur_end); cur_end = e0
+        steps.append({"gpu_span_ms": round(span / 1e6, 2), "gpu_busy_ms": round(busy / 1e6, 2), "busy_frac": round(busy / span, 4), "kernels": len(seg)})
+    steady = [x for x in steps if x["gpu_span_ms"] < 2 * min(y["gpu_span_ms"] for y in steps)] if steps else []
+    out["gpu_timeline_per_step"] = steady
+    if steady:
+        out["gpu_busy_frac_of_step"] = round(sum(x["gpu_busy_ms"] for x in steady) / sum(x["gpu_span_ms"] for x in steady), 4)
+        out["gpu_busy_note"] = ("from the kernel trace's own timestamps: step = one lcp_adjacent_kernel to the next (the span includes the host's trie build and "
+                                "planning at the step boundary); under rocprofv3 tracing, which slows the host side")
 hs = first("hip/**/*hip_api_stats.csv") or first("hip/**/*hip_stats.csv")
 hb = bench_line(os.path.join(root, "bench_under_hiptrace.json"))
 if hs and hb:
