@@ -24,7 +24,7 @@ def _init(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
-def _dp_worker(rank, world, port, name, q, overlapped=False, one_leaf=False):
+def _dp_worker(rank, world, port, name, q, overlapped=False, one_leaf=False, stack_block=0):
     import sys
     sys.path.insert(0, os.path.dirname(__file__)); sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
     import cases
@@ -52,6 +52,10 @@ def _dp_worker(rank, world, port, name, q, overlapped=False, one_leaf=False):
     if ids:
         t.backward_permute()
     eng = tree_training_engine.TreeTrainingEngine(model.config, "cpu", torch.float32, 4096)
+    ops.stack_attention = hostmirror._cpu_stack_attention
+    block = 2048
+    if stack_block:                   # block-wise engine: every parameter accumulates once per block, the reducer must wait for the last one
+        eng.mode, block = "stack", stack_block
     if overlapped:
         # tiny buckets: several collectives are in flight while the backward is still running; a second step re-uses the hooks;
         # every param.grad is a view of a persistent flat buffer that is reduced in place
@@ -59,11 +63,11 @@ def _dp_worker(rank, world, port, name, q, overlapped=False, one_leaf=False):
         assert len(red.buckets) > 2
         for _ in range(2):
             red.zero_grad()
-            red.start(); loss = eng.backward(model, t, mo.default_loss, 2048); red.finish()
+            red.start(); loss = eng.backward(model, t, mo.default_loss, block); red.finish()
         assert all(p.grad.data_ptr() == v.data_ptr() for p, v in red._views)
         red.close()
     else:
-        loss = eng.backward(model, t, mo.default_loss, 2048)
+        loss = eng.backward(model, t, mo.default_loss, block)
         dp.allreduce_grads(model.parameters())
     lt = torch.tensor([loss], dtype=torch.float64); dist.all_reduce(lt)
     torch.save({"loss": float(lt), "ids": sorted(ids), "grads": {n: p.grad.clone() for n, p in model.named_parameters()} if rank == 0 else None},
@@ -88,6 +92,24 @@ def test_trie_sharded_dp_grads_equal_full_batch(name, overlapped):
     assert abs(loss - gold["bwd_bs2048_loss"]) < 2e-4 * abs(loss)
     for n, g in gold["bwd_bs2048_grads"].items():
         assert mo.grad_ratio(g, grads[n]) <= 3e-5, n
+
+
+def test_overlapped_reduce_waits_for_the_last_block_of_the_blockwise_engine():
+    """engine.mode = "stack" accumulates into every parameter once per popped block; the hook-driven reducer is deferred by the engine
+    and reduces in finish() — otherwise a bucket would go out after its parameters' FIRST accumulation."""
+    from oracle import model_oracle as mo
+    import tempfile
+    name = "d128_tree"
+    gold = torch.load(os.path.join(GOLD, "engine_tiny.pt"), weights_only=True)[name]
+    ctx = mp.get_context("spawn"); q = tempfile.mkdtemp(); port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, name, q, True, False, 16)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    res = torch.load(os.path.join(q, "rank0.pt"), weights_only=True)
+    assert abs(res["loss"] - gold["bwd_bs2048_loss"]) < 2e-4 * abs(res["loss"])
+    for n, g in gold["bwd_bs2048_grads"].items():
+        assert mo.grad_ratio(g, res["grads"][n]) <= 4e-5, n
 
 
 @pytest.mark.parametrize("overlapped", [False, True])
