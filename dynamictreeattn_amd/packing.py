@@ -145,6 +145,47 @@ def ktile_qend_host(plan: SegmentPlan, tile: int = KTILE) -> np.ndarray:
     return out.astype(np.int32)
 
 
+def _merge(ivs):
+    """Sorted union of half-open intervals."""
+    out = []
+    for b, e in sorted(x for x in ivs if x[1] > x[0]):
+        if out and b <= out[-1][1]:
+            out[-1] = (out[-1][0], max(out[-1][1], e))
+        else:
+            out.append((b, e))
+    return out
+
+
+def _intersect(a, b):
+    a, b = _merge(a), _merge(b)
+    out, i, j = [], 0, 0
+    while i < len(a) and j < len(b):
+        lo, hi = max(a[i][0], b[j][0]), min(a[i][1], b[j][1])
+        if hi > lo:
+            out.append((lo, hi))
+        if a[i][1] < b[j][1]:
+            i += 1
+        else:
+            j += 1
+    return out
+
+
+def _subtract(a, b):
+    """a minus b (both merged, sorted)."""
+    out = []
+    for lo, hi in a:
+        cur = lo
+        for b0, b1 in b:
+            if b1 <= cur or b0 >= hi:
+                continue
+            if b0 > cur:
+                out.append((cur, b0))
+            cur = max(cur, b1)
+        if cur < hi:
+            out.append((cur, hi))
+    return out
+
+
 def plan_qtile_runs(plan: SegmentPlan, tile: int = QTILE):
     """Key runs each query tile of `tile` packed rows must visit: (run_ptr int32 [nqt+1],
     runs int32 [nruns,4] = {key_begin, key_end, needs_mask, 0}).  A run is flagged maskless only when
@@ -171,20 +212,24 @@ def plan_qtile_runs(plan: SegmentPlan, tile: int = QTILE):
                     out.append((s, q0, 0, 0))
             out.append((q0, q1, 1, 0))
         else:
+            # the tile straddles segments i0..i1: keys that are ancestors of EVERY row of the tile (the intersection of the
+            # segments' ancestor sets, below the tile) need no mask; the rest of the union does
+            common = None
             ivs = []
             for i in range(i0, i1 + 1):
-                ivs.extend(plan.path_runs[i])
                 s, e = int(seg_off[i]), min(q1, int(seg_off[i + 1]))
-                if e > s:
-                    ivs.append((s, e))
-            ivs.sort()
-            cb, ce = ivs[0]
-            for b, e in ivs[1:]:
-                if b <= ce:
-                    ce = max(ce, e)
-                else:
-                    out.append((cb, ce, 1, 0)); cb, ce = b, e
-            out.append((cb, ce, 1, 0))
+                if e <= s:
+                    continue                                  # empty segment: no rows here
+                anc = list(plan.path_runs[i])
+                if s < q0:
+                    anc.append((s, q0))                       # the segment's own rows above the tile
+                common = anc if common is None else _intersect(common, anc)
+                ivs.extend(plan.path_runs[i]); ivs.append((s, e))
+            common = _merge([(b, min(e, q0)) for b, e in (common or []) if b < q0])
+            for b, e in common:
+                out.append((b, e, 0, 0))
+            for b, e in _subtract(_merge(ivs), common):
+                out.append((b, e, 1, 0))
         run_ptr.append(len(out))
     return np.asarray(run_ptr, np.int32), np.asarray(out, np.int32).reshape(-1, 4)
 
