@@ -38,6 +38,7 @@ from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine
 MODEL_NAME = {"qwen3-0.6b": "Qwen3-0.6B", "qwen3-4b": "Qwen3-4B"}
 PEAK_TFLOPS = 2500.0               # dense MFMA bf16 / f16 peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0              # HBM3E spec, same table (6 290 GB/s measured copy)
+T_START = time.time()
 ATTACH = {"w_logprobs": -1.0, "w_entropy": 0.1}      # run_all.py:11-14
 DKV_KERNEL = "tree_attn_bwd_dkv2_kernel"             # the dominant kernel as rocprofv3 names it (8-wave dK/dV)
 HBM_KERNELS = {"dta_logprob_entropy_fwd": "logprob_entropy_fwd_kernel", "dta_logprob_entropy_bwd": "logprob_entropy_bwd_kernel",
@@ -60,6 +61,12 @@ def build_model(cfg: dict, device, dtype, seed: int = 0):
             else:
                 p.copy_((torch.randn(p.shape, generator=g, device=device, dtype=torch.float32) * 0.02).to(dtype))
     return m.train()
+
+
+def note(rank: int, msg: str) -> None:
+    """Progress on stderr (rank 0): the JSON line on stdout stays the only stdout output."""
+    if rank == 0:
+        print(f"[bench +{time.time() - T_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def host_threads() -> int:
@@ -157,6 +164,8 @@ def main():
     local = local % max(n_dev, 1)               # rehearsal on a 1-GPU box: ranks share the card (gloo only, below)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if 0 < n_dev < world:                       # shared card: keep the ranks' caching allocators from oversubscribing the HBM
+        torch.cuda.set_per_process_memory_fraction(0.92 * n_dev / world, dev)      # (3 ranks without it: 144 s per step, paging)
     backend = None
     if world > 1:
         # RCCL ("nccl") needs one GPU per rank; DTA_BENCH_BACKEND=gloo rehearses the N>1 code path on one GPU
@@ -164,6 +173,7 @@ def main():
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
+    note(rank, f"world {world}, backend {backend}, device {dev}")
     dtype = torch.float16 if wide else torch.bfloat16                     # BASELINE config 5 is fp16
     cfg = synth.QWEN3_0P6B if args.model == "qwen3-0.6b" else synth.QWEN3_4B
     model = build_model(cfg, dev, dtype)
@@ -245,6 +255,7 @@ def main():
     # {name}_bin{k}.pt ahead of the runs, exp/exp_dp.py:43-49) and its timed region is trie build + permute + engine call per bin
     # (run.py:90-108): same here — bins are planned before the clock starts, everything from TokenTrie(...) on is timed.
     total_steps = warmup + steps
+    note(rank, "model built; planning the per-rank batches")
     weak = []
     for s in range(total_steps):
         if tp:
@@ -257,6 +268,7 @@ def main():
             weak.append([seqs[i] for i in dp.my_bin(seqs, rank, world, "backward", args.block_size)])
     # library warm-up (not steps): hipBLASLt resolves a solution and loads its code object per exact GEMM shape on first use, and the
     # packed row count differs from call to call; the row counts come from trie statistics computed before the clock starts
+    note(rank, "batches planned; warming the GEMM shapes")
     if engine.mode != "stack":
         rows = set()
         for b in weak:
@@ -267,10 +279,12 @@ def main():
             engine.warm_gemm_shapes(model, rows)
     for s in range(warmup):
         step(weak[s])
+        note(rank, f"warm-up step {s + 1}/{warmup} done")
     zero()
     acc = new_acc()
     wall = timed(weak[warmup:], acc)
     wall, n_tokens, n_tree, pairs = reduce_stats(wall, acc)
+    note(rank, f"timed leg done: {steps} steps in {wall:.2f}s")
     engine_mode = engine.last_mode
     peak_hbm = torch.cuda.max_memory_allocated(dev)
 
@@ -283,6 +297,7 @@ def main():
     ms = timer.totals_ms()
     nbytes = timer.totals_bytes()
     wall_r, _, _, _ = reduce_stats(wall_r, acc_r)
+    note(rank, "roofline leg done")
     pairs_r = acc_r["pairs"]                                  # this rank's pairs: its own kernels' work
     L, Hq, D = cfg["num_hidden_layers"], cfg["num_attention_heads"], cfg["head_dim"]
 
@@ -335,6 +350,7 @@ def main():
             _, tc = step(mine, {"n_tokens": 0, "n_tree_tokens": 0, "pairs": 0, "split_times": True})
             torch.cuda.synchronize()
             t_tot.append(time.time() - t0); t_cmp.append(tc); tok += n_tok
+        note(rank, "strong-scaling leg done")
         tt = torch.tensor([t_tot, t_cmp], device=dev, dtype=torch.float64)        # [2, calls]
         mx = tt.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tt.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)

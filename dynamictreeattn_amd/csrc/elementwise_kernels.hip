@@ -309,7 +309,7 @@ extern "C" int dta_rmsnorm_fwd(const void* x, const void* delta, const void* w, 
 }
 
 /* dw_partial: float [dta_rmsnorm_bwd_blocks(R), H]; the caller sums it over dim 0. */
-extern "C" int dta_rmsnorm_bwd_blocks(int32_t R) { return row_blocks(R, 4, 512); }
+extern "C" int dta_rmsnorm_bwd_blocks(int32_t R) { return row_blocks(R, 4, 2048); }
 extern "C" int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dres, const float* rstd, void* dx, float* dw_partial,
                                int32_t R, int32_t H, int32_t dtype, void* stream) {
   if (!x || !w || !dy || !rstd || !dx || !dw_partial || R <= 0 || H <= 0) return DTA_EINVAL;
@@ -317,7 +317,7 @@ extern "C" int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, con
   if (!al16(x) || !al16(w) || !al16(dy) || !al16(dx) || (dres && !al16(dres))) return DTA_EALIGN;
   hipStream_t st_ = static_cast<hipStream_t>(stream);
   DTA_REFUSE_IF_PRIOR_ERROR();
-  const dim3 grid(row_blocks(R, 4, 512)), block(256);
+  const dim3 grid(row_blocks(R, 4, 2048)), block(256);
   if (H <= 4096) {
     if (dtype == DTA_BF16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_BF16, 8>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
     else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F16, 8>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
