@@ -1,0 +1,1325 @@
+// =====================================================================================================================
+// FROZEN EXPERIMENT (round 2) - not built into libdta_mi355x.so.  The product translation unit plus `tree_attn_bwd_dkv3_kernel`:
+// dK/dV with ONE wave per SIMD, 64 keys per wave, S/dP through inline-asm VGPR-form MFMAs and a hand-placed 64-gap schedule.
+// Bit-identical to the product kernel in tests/test_gpu_attention.py and within +-1 % of its time.
+// A/B build:  hipcc --offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -DDTA_DKV3 -o build/libdta_dkv3.so \
+//               dynamictreeattn_amd/csrc/diag/tree_attn_dkv3_experiment.hip dynamictreeattn_amd/csrc/{trie,elementwise,logprob}_kernels.hip
+//             DTA_LIB=$PWD/build/libdta_dkv3.so python scripts/attn_bench.py 10
+// Timing-only switches (results wrong): -DKV3_T_VALU=0 -DKV3_T_LD=0 -DKV3_T_TR=0 -DKV3_TIMING_DMA=0 -DKV3_TIMING_NOBARRIER
+// =====================================================================================================================
+// Tree attention forward / backward for gfx950 (MI355X, CDNA4).  head_dim = 128, bf16 or f16.
+//
+// One kernel family serves both forms of the reference's "node attends to its ancestor path":
+//   * packed trie (DFS pre-order): key s visible to query t  <=>  s <= t < subtree_end[s]
+//   * stack form (tree_training_engine.py:171-186): subtree_end == NULL, q_offset = start
+//
+// Tiling (wave64, v_mfma_f32_32x32x16, two waves per SIMD everywhere):
+//   fwd / dQ : workgroup = 8 waves = 128 query rows x the TWO query heads of one kv group (4 waves = 128 rows of one
+//              head when the group is odd); each wave owns 32 rows with the QUERY ON THE MFMA LANE (S^T = K.Q^T), so
+//              the softmax row statistics are lane-local and the S^T accumulator is directly the B operand of
+//              O^T += V^T.P^T / dQ^T += K^T.dS^T.  Both heads share the staged 64-key K/V tiles.
+//   dK/dV    : workgroup = 8 waves = 128 keys of one kv head with the KEY ON THE LANE (S = Q.K^T): the two 4-wave groups
+//              own the same keys and split every 64-row query tile; dK^T/dV^T live in 128 accumulator registers per wave
+//              across the whole query sweep (all query heads of the GQA group); the K/V fragments sit in LDS in fragment
+//              order.  Heavy key tiles are cut into split-Q work units whose fp32 slabs a finalize launch sums in order:
+//              no atomics, bitwise reproducible.
+//   Tiles (K/V for fwd, Q/dO for dK/dV) go global -> LDS by LDS-DMA issued from INLINE ASM (dma_* below) into one
+//   XOR-swizzled 256-B-row image that serves BOTH row reads (ds_read_b128) and transposed reads (ds_read_b64_tr_b16);
+//   the dQ kernel stages through registers (issue early, write late).
+//
+// Why inline asm for the DMA: with the builtin, hipcc (ROCm 7.2) waits `vmcnt(0)` for the in-flight prefetch of the
+// NEXT tile in front of LDS reads of the CURRENT one (before the first ds_read when the kernel has a second __shared__
+// object, before the first transposed / float4 read otherwise) - the prefetch was exposed on every tile.  An asm DMA is
+// outside hipcc's bookkeeping (cdna guide 5.7): the only wait is our own `s_waitcnt vmcnt(0)` in front of the
+// tile-end barrier, so a tile's DMA has the whole compute phase of the previous tile to land.
+//
+// Lane maps used here were verified on hardware by tests/micro/mfma_layout_probe.hip.
+// The round-1 ablation switches (-DDTA_ABL) and the retired 4-wave dK/dV kernel live in csrc/diag/ (not built).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "../dta_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector (HIP's uint4 class kept staging arrays in scratch)
+
+template <int DT> struct Ty;
+template <> struct Ty<DTA_BF16> {
+  using e = __bf16; using v8 = bf16x8; using v4 = bf16x4;
+  static __device__ __forceinline__ f32x16 mma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Ty<DTA_F16> {
+  using e = _Float16; using v8 = f16x8; using v4 = f16x4;
+  static __device__ __forceinline__ f32x16 mma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+struct AttnParams {
+  const void *q, *k, *v, *o, *dout;
+  void *out, *dq, *dk, *dv;
+  float *lse_w; const float* lse_r; float* delta;
+  const int32_t *subtree_end, *run_ptr, *runs, *ktile_qend;
+  const int32_t *dkv_units, *dkv_splits; float* dkv_ws;     // split-Q work units of the dK/dV sweep (NULL: one unit per key tile)
+  int32_t Tq, Tk, q_offset, Hq, Hkv, group;
+  int64_t q_st, q_sh, kv_st, kv_sh, v_st, v_sh, o_st, o_sh, dq_st, dq_sh, dkv_st, dkv_sh;
+  float scale; int32_t accumulate; int32_t ktile;
+};
+
+constexpr int TILE_BYTES = 64 * 256;           // 64 rows x 128 x 2 B
+constexpr float LOG2E = 1.4426950408889634f;
+
+// Byte offset of 16-B chunk `ch` (0..15) of row `row` in a [rows][128 x 16-bit] image with 256-B rows.
+// The XOR makes both the 32x32x16 row reads (ds_read_b128) and the transposed reads conflict-free.
+__device__ __forceinline__ int img_off(int row, int ch) {
+  return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+template <class V8> __device__ __forceinline__ V8 row_frag(const char* img, int row, int ch) {
+  return *reinterpret_cast<const V8*>(img + img_off(row, ch));
+}
+
+__device__ __forceinline__ s16x4 tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+// A-operand fragment read TRANSPOSED from the image: A[m = 32*mb + (lane&31)][kk], where the 16-deep
+// k-step covers image rows R0..R0+15 in the accumulator-as-operand order
+// (element j of lane half h <-> image row R0 + 8*(j>>2) + 4*h + (j&3)) and m indexes image columns.
+template <class V8> __device__ __forceinline__ V8 tr_frag(const char* img, int R0, int mb, int lane) {
+  const int G = lane >> 4, hh = lane >> 5, i = lane & 15, qd = i >> 2, p = i & 3;
+  const int ch = 4 * mb + 2 * (G & 1) + (p >> 1);
+  const int ra = R0 + 4 * hh + qd;
+  s16x4 lo = tr_read(img + img_off(ra, ch) + 8 * (p & 1));
+  s16x4 hi = tr_read(img + img_off(ra + 8, ch) + 8 * (p & 1));
+  s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(V8, both);
+}
+
+// accumulator registers 8*s2 .. 8*s2+7 -> 16-bit fragment of k-step s2 (s2 = 0,1) of a 32-row block
+template <int DT> __device__ __forceinline__ typename Ty<DT>::v8 pack_half(const f32x16& x, int s2) {
+  typename Ty<DT>::v8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (typename Ty<DT>::e)x[8 * s2 + j];
+  return r;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// ---- iterator over the 64-key tiles of a query tile's run list --------------------------------
+struct TileIter {
+  const int32_t* runs; int ri, re;      // run cursor
+  int k0, kend, flag;                   // current tile
+  int diag_first_q;                     // NULL-run mode: packed index of the tile's first query
+  __device__ __forceinline__ bool load_run() {
+    while (ri < re) {
+      k0 = __builtin_amdgcn_readfirstlane(runs[4 * ri]); kend = __builtin_amdgcn_readfirstlane(runs[4 * ri + 1]);
+      flag = __builtin_amdgcn_readfirstlane(runs[4 * ri + 2]);       // workgroup-uniform: keep the cursor in SGPRs
+      if (k0 < kend) return true;
+      ++ri;
+    }
+    return false;
+  }
+  __device__ __forceinline__ bool advance() {          // to the next tile; false when exhausted
+    k0 += 64;
+    if (k0 < kend) return true;
+    if (runs == nullptr) return false;
+    ++ri;
+    return load_run();
+  }
+  __device__ __forceinline__ bool masked() const {
+    if (runs == nullptr) return (k0 + 63 > diag_first_q) || (k0 + 64 > kend);
+    return flag != 0 || (k0 + 64 > kend);
+  }
+};
+
+// -------------------------------------------------------------------------------------------------
+// Staging macros (no lambdas: captured arrays were demoted to scratch by hipcc).
+// A 64-row x 128-col tile pair (A image + B image, 32 KB) is moved by NT threads; every thread owns
+// CPT 16-byte chunks of each image: chunk id = tid + NT*i -> row = id >> 4, chunk-in-row = id & 15.
+// -------------------------------------------------------------------------------------------------
+#define DTA_STAGE_LOAD(REGA, REGB, BASEA, BASEB, STRIDE_A, STRIDE_B, ROW0, ROWMAX, NT, CPT)                \
+  _Pragma("unroll") for (int i_ = 0; i_ < (CPT); ++i_) {                                                  \
+    const int id_ = tid + (NT) * i_, row_ = id_ >> 4, ch_ = id_ & 15;                                      \
+    int gr_ = (ROW0) + row_; gr_ = gr_ < (ROWMAX) ? gr_ : (ROWMAX) - 1;                                    \
+    REGA[i_] = *reinterpret_cast<const u32x4*>((BASEA) + (int64_t)gr_ * (STRIDE_A) + ch_ * 8);             \
+    REGB[i_] = *reinterpret_cast<const u32x4*>((BASEB) + (int64_t)gr_ * (STRIDE_B) + ch_ * 8);             \
+  }
+#define DTA_STAGE_WRITE(REGA, REGB, IMGA, IMGB, NT, CPT)                                                  \
+  _Pragma("unroll") for (int i_ = 0; i_ < (CPT); ++i_) {                                                  \
+    const int id_ = tid + (NT) * i_, row_ = id_ >> 4, ch_ = id_ & 15;                                      \
+    *reinterpret_cast<u32x4*>((IMGA) + img_off(row_, ch_)) = REGA[i_];                                     \
+    *reinterpret_cast<u32x4*>((IMGB) + img_off(row_, ch_)) = REGB[i_];                                     \
+  }
+
+constexpr int SE_BYTES = 256;                                       // 64 x int32 subtree_end of the staged keys
+constexpr int QK_LDS = 2 * (2 * TILE_BYTES + SE_BYTES);            // double-buffered {K image, V image, se}
+
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// Per-lane byte offsets of every fragment read inside one image, computed once: the XOR swizzle depends on the
+// lane only (row blocks of 32 and k-steps of 16 rows leave row&3 and (row>>2)&3 unchanged), so inside the tile
+// loop every ds_read is <lane offset register> + <compile-time immediate>.
+struct FragOffs { int row[8]; int tr[8]; };
+__device__ __forceinline__ FragOffs frag_offsets(int lane) {
+  FragOffs o;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) o.row[s] = img_off(r, 2 * s + h);
+  const int G = lane >> 4, i = lane & 15, qd = i >> 2, pp = i & 3;
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    const int ch = 4 * mb + 2 * (G & 1) + (pp >> 1);
+    o.tr[mb] = img_off(4 * h + qd, ch) + 8 * (pp & 1);
+    o.tr[4 + mb] = img_off(4 * h + qd + 8, ch) + 8 * (pp & 1);
+  }
+  return o;
+}
+template <class V8> __device__ __forceinline__ V8 tr_pair(const char* lo_p, const char* hi_p) {
+  s16x4 lo = tr_read(lo_p);
+  s16x4 hi = tr_read(hi_p);
+  s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(V8, both);
+}
+template <class V8> __device__ __forceinline__ V8 tr_frag_o(const char* img_r0, const FragOffs& o, int mb) {
+  s16x4 lo = tr_read(img_r0 + o.tr[mb]);
+  s16x4 hi = tr_read(img_r0 + o.tr[4 + mb]);
+  s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(V8, both);
+}
+
+// ---- LDS-DMA from inline asm (see the file header for why) ---------------------------------------------------------
+// A wave instruction lands 64 x 16 B = 1 KiB = 4 image rows lane-linearly at M0, so the image's XOR swizzle goes on the
+// per-lane SOURCE chunk.  The global address is <scalar base> + <32-bit per-lane byte offset>: per tile only the base
+// moves.  `s_nop 4` covers a base that was just produced by v_readfirstlane (VALU-written SGPR -> VMEM, 5 wait states),
+// `s_nop 0` the M0 write -> LDS-DMA hazard.  hipcc does not count these loads: DMA_WAIT() before the barrier that
+// publishes the tile is the only thing that orders them.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(p);
+}
+// pieces {0, 1} of image A (at lds, lds + 1 KiB) and of image B (at lds + TILE_BYTES, + 1 KiB)
+__device__ __forceinline__ void dma_pair2(uint32_t oa0, uint32_t oa1, const void* ba, uint32_t ob0, uint32_t ob1, const void* bb, uint32_t lds) {
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 m0, %6\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %4\n\t"
+      "s_add_u32 m0, %6, 0x4000\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %5\n\t"
+      "s_add_u32 m0, %6, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %4\n\t"
+      "s_add_u32 m0, %6, 0x4400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %3, %5"
+      :: "v"(oa0), "v"(oa1), "v"(ob0), "v"(ob1), "s"(ba), "s"(bb), "s"(lds) : "memory", "scc");
+}
+// 64 dwords (row constants of a tile: subtree_end, lse, delta)
+__device__ __forceinline__ void dma_dword(uint32_t off, const void* base, uint32_t lds) {
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(off), "s"(base), "s"(lds) : "memory");
+}
+#define DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// Byte offset of this lane's 16-B chunk of image row `row` (rows of `stride` elements of `esz` bytes), swizzled
+__device__ __forceinline__ uint32_t dma_src_off(int row, int img_row, int lane, int64_t stride, int esz) {
+  const int ch = (lane & 15) ^ (((img_row & 3) << 2) | ((img_row >> 2) & 3));
+  return (uint32_t)((row * stride + ch * 8) * (int64_t)esz);
+}
+
+// K/V tile pair of the forward: NW waves move the 16 + 16 pieces; wave w owns pieces (16/NW)*w .. of both images.
+// subtree_end of the 64 keys goes by 4-byte DMA from wave 0; keys at or beyond the run end are excluded by the
+// caller's `k <= min(q, kend-1)` test, not by a sentinel.
+#define DTA_KV_OFFSETS(NW)                                                                                 \
+  uint32_t voff_k[16 / (NW)], voff_v[16 / (NW)];                                                           \
+  _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) {                                               \
+    const int row_ = 4 * (wave * (16 / (NW)) + i_) + (lane >> 4);                                          \
+    voff_k[i_] = dma_src_off(row_, row_, lane, p.kv_st, sizeof(e));                                        \
+    voff_v[i_] = dma_src_off(row_, row_, lane, p.v_st, sizeof(e)); }
+#define DTA_KV_DMA(BASE, K0, NW)                                                                           \
+  { char* base_ = (BASE); const int k0_ = (K0);                                                            \
+    if (wave == 0) {                                                                                       \
+      if (p.subtree_end) { int ki_ = k0_ + lane; ki_ = ki_ < p.Tk ? ki_ : p.Tk - 1;                        \
+        dma_dword((uint32_t)ki_ * 4u, p.subtree_end, lds_addr(base_ + 2 * TILE_BYTES)); }                  \
+      else reinterpret_cast<int*>(base_ + 2 * TILE_BYTES)[lane] = 0x7fffffff; }                            \
+    const char* kb_ = reinterpret_cast<const char*>(kbase) + (int64_t)k0_ * p.kv_st * (int64_t)sizeof(e);  \
+    const char* vb_ = reinterpret_cast<const char*>(vbase) + (int64_t)k0_ * p.v_st * (int64_t)sizeof(e);   \
+    uint32_t ok_[16 / (NW)], ov_[16 / (NW)];                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) { ok_[i_] = voff_k[i_]; ov_[i_] = voff_v[i_]; } \
+    if (k0_ + 64 > p.Tk) {                         /* ragged last tile of the tensor: clamp the row per lane */ \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) {                                           \
+        const int row_ = 4 * (wave * (16 / (NW)) + i_) + (lane >> 4);                                      \
+        const int rr_ = k0_ + row_ < p.Tk ? row_ : p.Tk - 1 - k0_;                                         \
+        ok_[i_] = dma_src_off(rr_, row_, lane, p.kv_st, sizeof(e)); ov_[i_] = dma_src_off(rr_, row_, lane, p.v_st, sizeof(e)); } } \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); i_ += 2)                                            \
+      dma_pair2(ok_[i_], ok_[i_ + 1], kb_, ov_[i_], ov_[i_ + 1], vb_, lds_addr(base_ + (wave * (16 / (NW)) + i_) * 1024)); }
+
+// =================================================================================================
+// forward.  HPB = query heads of one kv group handled by a workgroup (waves 4*hb .. 4*hb+3 own head hb);
+// they share the staged K/V tiles.  One barrier per 64-key tile, LDS double buffered, tile loop unrolled
+// over the two buffers so that every LDS address is lane-offset + immediate.
+// =================================================================================================
+template <int DT, int HPB>
+__global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams p) {
+  using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
+  constexpr int NW = 4 * HPB, BUF = 2 * TILE_BYTES + SE_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[QK_LDS];
+
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform values live in SGPRs
+  const int hb = wave >> 2, rw = wave & 3;
+  const int bid = blockIdx.x;
+  const int hgroups = p.group / HPB;
+  const int kvh = bid % p.Hkv; const int rest = bid / p.Hkv; const int hgb = rest % hgroups;
+  const int nqt = (p.Tq + DTA_QTILE - 1) / DTA_QTILE;
+  const int qt = nqt - 1 - rest / hgroups;                          // deepest (heaviest) query tiles first
+  const int hq = kvh * p.group + hgb * HPB + hb;
+  const int q0 = qt * DTA_QTILE;
+  const int qrow = q0 + rw * 32 + r;
+  const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
+  const int qidx = p.q_offset + qrow;
+
+  TileIter it; it.runs = p.runs; it.diag_first_q = p.q_offset + q0;
+  if (p.runs) { it.ri = p.run_ptr[qt]; it.re = p.run_ptr[qt + 1]; if (!it.load_run()) return; }
+  else { it.ri = 0; it.re = 1; it.k0 = 0; it.flag = 1; int last = p.q_offset + (q0 + DTA_QTILE < p.Tq ? q0 + DTA_QTILE : p.Tq); it.kend = last < p.Tk ? last : p.Tk; if (it.kend <= 0) return; }
+
+  const e* qp = reinterpret_cast<const e*>(p.q) + (int64_t)qrow_c * p.q_st + (int64_t)hq * p.q_sh;
+  v8 qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const v8*>(qp + 16 * s + 8 * h);
+
+  const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
+  const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.v_sh;
+  const FragOffs offs = frag_offsets(lane);
+  DTA_KV_OFFSETS(NW)
+
+  f32x16 O[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) O[db][g] = 0.f;
+  float m = -1e30f, lsum = 0.f;
+  const float c = p.scale * LOG2E;
+
+  int ck0 = it.k0, ckend = it.kend; bool cmask = it.masked();
+  DTA_KV_DMA(smem, it.k0, NW)
+  bool has_next = it.advance();
+  DMA_WAIT(); __syncthreads();
+
+  // one tile out of buffer BUFI (compile-time): prefetch the next tile into the other buffer, S^T, softmax, PV
+#define FWD_TILE(BUFI)                                                                                     \
+  {                                                                                                        \
+    int nk0_ = 0, nkend_ = 0; bool nmask_ = false;                                                         \
+    if (has_next) { nk0_ = it.k0; nkend_ = it.kend; nmask_ = it.masked(); DTA_KV_DMA(smem + (1 - (BUFI)) * BUF, it.k0, NW) } \
+    const char* Ks = smem + (BUFI) * BUF; const char* Vs = Ks + TILE_BYTES;                                \
+    const int* se_s = reinterpret_cast<const int*>(Ks + 2 * TILE_BYTES);                                   \
+    f32x16 X[2];                                                                                           \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                     \
+      _Pragma("unroll") for (int g = 0; g < 16; ++g) X[kb][g] = 0.f;                                       \
+      _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                        \
+        X[kb] = T::mma(*reinterpret_cast<const v8*>(Ks + 8192 * kb + offs.row[s]), qf[s], X[kb]); \
+    }                                                                                                      \
+    if (cmask) {                                                                                           \
+      const int qlim = qidx < ckend ? qidx : ckend - 1;      /* keys at or beyond the run end never count */ \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                     \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                 \
+          const int kl = 32 * kb + 8 * gq + 4 * h;                                                         \
+          const int4 se4 = *reinterpret_cast<const int4*>(se_s + kl);                                      \
+          const int sev[4] = {se4.x, se4.y, se4.z, se4.w};                                                 \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+            const bool ok = (ck0 + kl + j <= qlim) && (qidx < sev[j]);                                     \
+            X[kb][4 * gq + j] = ok ? X[kb][4 * gq + j] : -INFINITY;                                        \
+          }                                                                                                \
+        }                                                                                                  \
+    }                                                                                                      \
+    float mx = max3(X[0][0], X[0][1], X[0][2]);                                                            \
+    _Pragma("unroll") for (int g = 3; g < 15; g += 2) mx = max3(mx, X[0][g], X[0][g + 1]);                 \
+    mx = fmaxf(mx, X[0][15]);                                                                              \
+    _Pragma("unroll") for (int g = 0; g < 16; g += 2) mx = max3(mx, X[1][g], X[1][g + 1]);                 \
+    mx = fmaxf(mx, __shfl_xor(mx, 32));                                                                    \
+    const float mc = mx * c;                                                                               \
+    if (__any(mc > m)) {                       /* O is rescaled only when some row's maximum really grew */ \
+      const float mnew = fmaxf(m, mc);                                                                     \
+      const float alpha = fast_exp2(m - mnew);                                                             \
+      m = mnew; lsum *= alpha;                                                                             \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db)                                                     \
+        _Pragma("unroll") for (int g = 0; g < 16; ++g) O[db][g] *= alpha;                                  \
+    }                                                                                                      \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                       \
+      _Pragma("unroll") for (int g = 0; g < 16; ++g) { const float pv = fast_exp2(__builtin_fmaf(X[kb][g], c, -m)); lsum += pv; X[kb][g] = pv; } \
+    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                     \
+      const v8 pb = pack_half<DT>(X[s4 >> 1], s4 & 1);                                                     \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) O[db] = T::mma(tr_frag_o<v8>(Vs + 4096 * s4, offs, db), pb, O[db]); \
+    }                                                                                                      \
+    DMA_WAIT(); __syncthreads();               /* the next tile has landed in every wave's view */          \
+    if (!has_next) break;                                                                                  \
+    ck0 = nk0_; ckend = nkend_; cmask = nmask_;                                                            \
+    has_next = it.advance();                                                                               \
+  }
+  while (true) {
+    FWD_TILE(0)
+    FWD_TILE(1)
+  }
+#undef FWD_TILE
+
+  lsum += __shfl_xor(lsum, 32);
+  const float inv = 1.f / lsum;
+  if (qrow < p.Tq) {
+    e* op = reinterpret_cast<e*>(p.out) + (int64_t)qrow * p.o_st + (int64_t)hq * p.o_sh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        v4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (e)(O[db][4 * gq + j] * inv);
+        *reinterpret_cast<v4*>(op + 32 * db + 8 * gq + 4 * h) = w;
+      }
+    if (h == 0) p.lse_w[(int64_t)hq * p.Tq + qrow] = m + __builtin_amdgcn_logf(lsum);   // v_log_f32 = log2
+  }
+}
+
+// =================================================================================================
+// backward part 1: delta + dQ   (query tile owns the workgroup; same sweep as the forward)
+// =================================================================================================
+template <int DT, int HPB>
+__global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_kernel(AttnParams p) {
+  using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
+  __shared__ __attribute__((aligned(16))) char smem[QK_LDS];
+
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform values live in SGPRs
+  const int hb = wave >> 2, rw = wave & 3;
+  const int bid = blockIdx.x;
+  const int hgroups = p.group / HPB;
+  const int kvh = bid % p.Hkv; const int rest = bid / p.Hkv; const int hgb = rest % hgroups;
+  const int nqt = (p.Tq + DTA_QTILE - 1) / DTA_QTILE;
+  const int qt = nqt - 1 - rest / hgroups;
+  const int hq = kvh * p.group + hgb * HPB + hb;
+  const int q0 = qt * DTA_QTILE;
+  const int qrow = q0 + rw * 32 + r;
+  const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
+  const int qidx = p.q_offset + qrow;
+
+  const e* qp = reinterpret_cast<const e*>(p.q) + (int64_t)qrow_c * p.q_st + (int64_t)hq * p.q_sh;
+  const e* dop = reinterpret_cast<const e*>(p.dout) + (int64_t)qrow_c * p.o_st + (int64_t)hq * p.o_sh;
+  const e* op = reinterpret_cast<const e*>(p.o) + (int64_t)qrow_c * p.o_st + (int64_t)hq * p.o_sh;
+  v8 qf[8], dof[8];
+  float dsum = 0.f;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    qf[s] = *reinterpret_cast<const v8*>(qp + 16 * s + 8 * h);
+    dof[s] = *reinterpret_cast<const v8*>(dop + 16 * s + 8 * h);
+    const v8 of = *reinterpret_cast<const v8*>(op + 16 * s + 8 * h);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsum += (float)dof[s][j] * (float)of[j];
+  }
+  dsum += __shfl_xor(dsum, 32);
+  const float delta = dsum;
+  const float lse2 = p.lse_r[(int64_t)hq * p.Tq + qrow_c];
+  if (h == 0 && qrow < p.Tq) p.delta[(int64_t)hq * p.Tq + qrow] = -delta;    // workspace holds -delta: the dK/dV kernel loads it as the INITIAL dP accumulator
+
+  TileIter it; it.runs = p.runs; it.diag_first_q = p.q_offset + q0;
+  bool any = true;
+  if (p.runs) { it.ri = p.run_ptr[qt]; it.re = p.run_ptr[qt + 1]; any = it.load_run(); }
+  else { it.ri = 0; it.re = 1; it.k0 = 0; it.flag = 1; int last = p.q_offset + (q0 + DTA_QTILE < p.Tq ? q0 + DTA_QTILE : p.Tq); it.kend = last < p.Tk ? last : p.Tk; any = it.kend > 0; }
+
+  const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
+  const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.v_sh;
+  constexpr int NW = 4 * HPB, BUF = 2 * TILE_BYTES + SE_BYTES;
+  DTA_KV_OFFSETS(NW)                      // K/V tiles by LDS-DMA as in the forward (no staging registers, no ds_write)
+
+  f32x16 DQ[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) DQ[db][g] = 0.f;
+  const float c = p.scale * LOG2E;
+
+  const float delta_s = delta * p.scale;
+  if (any) {
+    int ck0 = it.k0, ckend = it.kend; bool cmask = it.masked();
+    DTA_KV_DMA(smem, it.k0, NW)
+    bool has_next = it.advance();
+    DMA_WAIT(); __syncthreads();
+    int cur = 0;
+    while (true) {
+      int nk0 = 0, nkend = 0; bool nmask = false;
+      if (has_next) { nk0 = it.k0; nkend = it.kend; nmask = it.masked(); DTA_KV_DMA(smem + (cur ^ 1) * BUF, it.k0, NW) }
+      const char* Ks = smem + cur * BUF; const char* Vs = Ks + TILE_BYTES;
+      const int* se_s = reinterpret_cast<const int*>(Ks + 2 * TILE_BYTES);
+      // one 32-key block at a time keeps S^T/dP^T at 32 live accumulators (2 waves per SIMD need <= 256 registers)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 X, DP;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { X[g] = 0.f; DP[g] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          X = T::mma(row_frag<v8>(Ks, 32 * kb + r, 2 * s + h), qf[s], X);
+          DP = T::mma(row_frag<v8>(Vs, 32 * kb + r, 2 * s + h), dof[s], DP);
+        }
+        // dS^T = P ∘ (dP·scale − delta·scale); the interval mask only on tiles of runs flagged partial
+        if (cmask) {
+          const int qlim = qidx < ckend ? qidx : ckend - 1;      // keys at or beyond the run end never count
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int kl = 32 * kb + 8 * gq + 4 * h;
+            const int4 se4 = *reinterpret_cast<const int4*>(se_s + kl);
+            const int sev[4] = {se4.x, se4.y, se4.z, se4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int g = 4 * gq + j;
+              const bool ok = (ck0 + kl + j <= qlim) && (qidx < sev[j]);
+              const float pv = ok ? fast_exp2(__builtin_fmaf(X[g], c, -lse2)) : 0.f;
+              X[g] = pv * __builtin_fmaf(DP[g], p.scale, -delta_s);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) X[g] = fast_exp2(__builtin_fmaf(X[g], c, -lse2)) * __builtin_fmaf(DP[g], p.scale, -delta_s);
+        }
+        // dQ^T[d][q] += K^T · dS^T
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const v8 db_ = pack_half<DT>(X, s2);
+#pragma unroll
+          for (int db = 0; db < 4; ++db) DQ[db] = T::mma(tr_frag<v8>(Ks, 32 * kb + 16 * s2, db, lane), db_, DQ[db]);
+        }
+      }
+      DMA_WAIT(); __syncthreads();
+      if (!has_next) break;
+      cur ^= 1; ck0 = nk0; ckend = nkend; cmask = nmask;
+      has_next = it.advance();
+    }
+  }
+  if (qrow < p.Tq) {
+    e* dqp = reinterpret_cast<e*>(p.dq) + (int64_t)qrow * p.dq_st + (int64_t)hq * p.dq_sh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        v4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (e)DQ[db][4 * gq + j];
+        *reinterpret_cast<v4*>(dqp + 32 * db + 8 * gq + 4 * h) = w;
+      }
+  }
+}
+
+// =================================================================================================
+// backward part 2: dK, dV.  Key tile owns the workgroup.
+// =================================================================================================
+// -------------------------------------------------------------------------------------------------
+// dK/dV with TWO waves per SIMD (8 waves): the two wave groups own the same 128 keys and split every 64-row query tile
+// between them (group g takes rows 32g..32g+31), so they share ONE double-buffered Q/dO image.  To fit 256 registers
+// the K/V fragments (pure MFMA B operands) live in LDS in fragment order (one lane-linear, conflict-free ds_read_b128
+// per use) instead of 64 registers.  The groups' partial dK/dV are summed through LDS in a fixed order at the end.
+// -------------------------------------------------------------------------------------------------
+constexpr int KV2_FRAGS = 4 * 16384;                                // 4 key slots x {K: 8 fragments x 1 KiB, V: 8 x 1 KiB}
+constexpr int KV2_BUF = 2 * TILE_BYTES + 512;
+constexpr int KV2_LDS = KV2_FRAGS + 2 * KV2_BUF + 16;                   // + se_min[4]: ONE __shared__ object (a second one makes hipcc drain vmcnt in front of every LDS read)
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p) {
+  using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
+  constexpr int KT = 128;
+  __shared__ __attribute__((aligned(16))) char smem_all[KV2_LDS];
+  const int tid8 = threadIdx.x, tid = tid8 & 255, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid8 >> 6);       // 0..7
+  const int grp = wave8 >> 2, wave = wave8 & 3;
+  char* kvs = smem_all + wave * 16384;                               // this key slot's K fragments (+8192: V)
+  char* smem = smem_all + KV2_FRAGS;                                 // the Q/dO buffers
+  const int bid = blockIdx.x;
+  const int kvh = bid % p.Hkv; const int unit = bid / p.Hkv;
+  const int kt = p.dkv_units ? p.dkv_units[4 * unit] : unit;
+  const int slab = p.dkv_units ? p.dkv_units[4 * unit + 3] : -1;
+  const int k0 = kt * KT;
+  const int q_hi = p.q_offset + p.Tq;
+  const int kidx = k0 + wave * 32 + r;
+  int se_l;
+  { const int kc = kidx < p.Tk ? kidx : p.Tk - 1;
+    int se = (kidx < p.Tk) ? (p.subtree_end ? p.subtree_end[kidx] : 0x7fffffff) : 0;
+    se_l = se < q_hi ? se : q_hi;
+    if (grp == 0) {                                                  // group 0 stages the fragments both groups read
+      const e* kp = reinterpret_cast<const e*>(p.k) + (int64_t)kc * p.kv_st + (int64_t)kvh * p.kv_sh;
+      const e* vp = reinterpret_cast<const e*>(p.v) + (int64_t)kc * p.v_st + (int64_t)kvh * p.v_sh;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        *reinterpret_cast<v8*>(kvs + s * 1024 + lane * 16) = *reinterpret_cast<const v8*>(kp + 16 * s + 8 * h);
+        *reinterpret_cast<v8*>(kvs + 8192 + s * 1024 + lane * 16) = *reinterpret_cast<const v8*>(vp + 16 * s + 8 * h);
+      }
+    } }
+  int* se_min_s = reinterpret_cast<int*>(smem_all + KV2_FRAGS + 2 * KV2_BUF);
+  { int mn = se_l;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
+    if (lane == 0 && grp == 0) se_min_s[wave] = mn; }
+  __syncthreads();
+  const int se_min = __builtin_amdgcn_readfirstlane(min(min(se_min_s[0], se_min_s[1]), min(se_min_s[2], se_min_s[3])));
+
+  const FragOffs offs = frag_offsets(lane);
+  f32x16 DK[4], DV[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { DK[db][g] = 0.f; DV[db][g] = 0.f; }
+
+  int qbeg, qend;
+  if (p.dkv_units) { qbeg = __builtin_amdgcn_readfirstlane(p.dkv_units[4 * unit + 1]); qend = __builtin_amdgcn_readfirstlane(p.dkv_units[4 * unit + 2]); }
+  else {
+    qbeg = k0 > p.q_offset ? k0 : p.q_offset;
+    qend = p.ktile_qend ? p.ktile_qend[kt] : q_hi; qend = qend < q_hi ? qend : q_hi;
+  }
+  const int ntile = qend > qbeg ? (qend - qbeg + 63) / 64 : 0;
+  const int total = ntile * p.group;
+  const float c = p.scale * LOG2E;
+
+  // tile DMA: 16 one-KiB pieces per image over 8 waves = 2 per wave per image (piece = 2*wave8 + i: rows 8*wave8 + 4*i ..);
+  // lse / delta rows (64 floats each) by 4-byte DMA from waves 0 / 1.
+  uint32_t voff_q[2], voff_d[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row_ = 8 * wave8 + 4 * i + (lane >> 4);
+    voff_q[i] = dma_src_off(row_, row_, lane, p.q_st, sizeof(e));
+    voff_d[i] = dma_src_off(row_, row_, lane, p.o_st, sizeof(e));
+  }
+  const uint32_t lds_tiles = lds_addr(smem);
+  // scalar cursor of the NEXT tile to stage: byte offsets of its first row in q / dout and float offset of its row
+  // constants; advanced by additions (64 rows down, or to row qbeg of the next query head) - no 64-bit multiplies per tile
+  const int64_t q_step = 64 * p.q_st * (int64_t)sizeof(e), d_step = 64 * p.o_st * (int64_t)sizeof(e);
+  const int64_t q_wrap = p.q_sh * (int64_t)sizeof(e) - ntile * q_step, d_wrap = p.o_sh * (int64_t)sizeof(e) - ntile * d_step;
+  int64_t q_cur = ((int64_t)(kvh * p.group) * p.q_sh + (int64_t)(qbeg - p.q_offset) * p.q_st) * (int64_t)sizeof(e);
+  int64_t d_cur = ((int64_t)(kvh * p.group) * p.o_sh + (int64_t)(qbeg - p.q_offset) * p.o_st) * (int64_t)sizeof(e);
+  int64_t c_cur = (int64_t)(kvh * p.group) * p.Tq;
+  int row_n = qbeg - p.q_offset, ti_n = 0;
+#define KV2_DMA(B)                                                                                         \
+  { const uint32_t lb_ = lds_tiles + (uint32_t)(B) * KV2_BUF;                                              \
+    if (wave8 < 2) { int qr_ = row_n + lane; qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1;   /* wave 0: lse[64], wave 1: delta[64] */ \
+      dma_dword((uint32_t)qr_ * 4u, (wave8 == 0 ? p.lse_r : p.delta) + c_cur, lb_ + 2 * TILE_BYTES + wave8 * 256); } \
+    uint32_t oq0_ = voff_q[0], oq1_ = voff_q[1], od0_ = voff_d[0], od1_ = voff_d[1];                       \
+    if (row_n + 64 > p.Tq) {                       /* ragged last tile of the tensor: clamp the row per lane */ \
+      const int ra_ = 8 * wave8 + (lane >> 4), rb_ = ra_ + 4;                                              \
+      const int ca_ = row_n + ra_ < p.Tq ? ra_ : p.Tq - 1 - row_n, cb_ = row_n + rb_ < p.Tq ? rb_ : p.Tq - 1 - row_n; \
+      oq0_ = dma_src_off(ca_, ra_, lane, p.q_st, sizeof(e)); oq1_ = dma_src_off(cb_, rb_, lane, p.q_st, sizeof(e)); \
+      od0_ = dma_src_off(ca_, ra_, lane, p.o_st, sizeof(e)); od1_ = dma_src_off(cb_, rb_, lane, p.o_st, sizeof(e)); } \
+    dma_pair2(oq0_, oq1_, reinterpret_cast<const char*>(p.q) + q_cur, od0_, od1_, reinterpret_cast<const char*>(p.dout) + d_cur, lb_ + wave8 * 2048); \
+    ++ti_n; row_n += 64; q_cur += q_step; d_cur += d_step;                                                 \
+    if (ti_n >= ntile) { ti_n = 0; row_n = qbeg - p.q_offset; q_cur += q_wrap; d_cur += d_wrap; c_cur += p.Tq; } }
+
+  // Per-lane LDS byte offsets of every fragment read of this wave group inside a tile buffer, computed once; the tile loop is
+  // unrolled over the two buffers so that the buffer offset is an instruction immediate (no per-tile address VALU).
+  int ar[8], at[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ar[j] = offs.row[j] + grp * (32 * 256); at[j] = offs.tr[j] + grp * (32 * 256); }
+  const int rc_off = (32 * grp + 4 * h) * 4;                            // this lane's first row constant (lse / -delta) inside a buffer
+
+  // one 64-row query tile out of buffer BUFI (compile-time)
+#define KV2_TILE(BUFI)                                                                                     \
+  {                                                                                                        \
+    const int ti = ti_c;                                                                                   \
+    ti_c += 1;                                                                                             \
+    if (ti_c >= ntile) ti_c = 0;                                                                           \
+    if (idx + 1 < total) KV2_DMA(1 - (BUFI))      /* lands while this tile computes; waited for at the tile end */ \
+    const char* tb = smem + (BUFI) * KV2_BUF;                                                              \
+    const char* rc = tb + 2 * TILE_BYTES + rc_off;                                                         \
+    const int qi0 = qbeg + 64 * ti + 32 * grp;                       /* packed index of this group's first row */ \
+    const bool full = (qbeg + 64 * ti >= k0 + KT - 1) && (qbeg + 64 * ti + 63 < se_min);   /* workgroup-uniform: no mask needed */ \
+    /* S starts at 0 (inline constant); dP starts at -delta, read from LDS straight into the accumulator registers:    \
+       p = exp2(c*S - lse),  dS/scale = p * dP'  with dP' = dO.V^T - delta  (the softmax scale of dS goes onto dK once, in the epilogue) */ \
+    f32x16 S, DP;                                                                                          \
+    _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                     \
+      const float4 d4 = *reinterpret_cast<const float4*>(rc + 256 + 32 * gq);                              \
+      DP[4 * gq] = d4.x; DP[4 * gq + 1] = d4.y; DP[4 * gq + 2] = d4.z; DP[4 * gq + 3] = d4.w;              \
+    }                                                                                                      \
+    _Pragma("unroll") for (int g = 0; g < 16; ++g) S[g] = 0.f;                                             \
+    _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                        \
+      const v8 aq = *reinterpret_cast<const v8*>(tb + ar[s]);                                              \
+      const v8 ad = *reinterpret_cast<const v8*>(tb + ar[s] + TILE_BYTES);                                 \
+      const v8 kfs = *reinterpret_cast<const v8*>(kvs + s * 1024 + lane * 16);                             \
+      const v8 vfs = *reinterpret_cast<const v8*>(kvs + 8192 + s * 1024 + lane * 16);                      \
+      S = T::mma(aq, kfs, S); DP = T::mma(ad, vfs, DP);                                                    \
+    }                                                                                                      \
+    float nl[16];                                                                                          \
+    _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                     \
+      const float4 l4 = *reinterpret_cast<const float4*>(rc + 32 * gq);                                    \
+      nl[4 * gq] = l4.x; nl[4 * gq + 1] = l4.y; nl[4 * gq + 2] = l4.z; nl[4 * gq + 3] = l4.w;              \
+    }                                                                                                      \
+    if (full) {                                                                                            \
+      _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                     \
+        const float pv = fast_exp2(__builtin_fmaf(S[g], c, -nl[g]));                                       \
+        S[g] = pv;                                                                                         \
+        DP[g] = pv * DP[g];                                                                                \
+      }                                                                                                    \
+    } else {                                                                                               \
+      _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                     \
+        const int qi = qi0 + 8 * (g >> 2) + 4 * h + (g & 3);                                               \
+        const bool ok = (kidx <= qi) && (qi < se_l);                                                       \
+        const float pv = ok ? fast_exp2(__builtin_fmaf(S[g], c, -nl[g])) : 0.f;                            \
+        S[g] = pv;                                                                                         \
+        DP[g] = pv * DP[g];                                                                                \
+      }                                                                                                    \
+    }                                                                                                      \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                     \
+      const v8 pb = pack_half<DT>(S, s2), sbf = pack_half<DT>(DP, s2);                                     \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                   \
+        const v8 adt = tr_pair<v8>(tb + at[db] + TILE_BYTES + 4096 * s2, tb + at[4 + db] + TILE_BYTES + 4096 * s2); \
+        const v8 aqt = tr_pair<v8>(tb + at[db] + 4096 * s2, tb + at[4 + db] + 4096 * s2);                  \
+        DV[db] = T::mma(adt, pb, DV[db]); DK[db] = T::mma(aqt, sbf, DK[db]);                               \
+      }                                                                                                    \
+    }                                                                                                      \
+    DMA_WAIT(); __syncthreads();                                                                           \
+    ++idx;                                                                                                 \
+  }
+
+  {
+    int ti_c = 0;
+    if (total > 0) KV2_DMA(0)
+    DMA_WAIT(); __syncthreads();
+    int idx = 0;
+    while (idx < total) {
+      KV2_TILE(0)
+      if (idx >= total) break;
+      KV2_TILE(1)
+    }
+  }
+#undef KV2_TILE
+#undef KV2_DMA
+  {
+    // group 1 hands its partial sums to group 0 through LDS, 32 accumulators (one d-block of dK and dV) at a time
+    float* red = reinterpret_cast<float*>(smem_all);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      if (grp == 1) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { red[g * 256 + tid] = DK[db][g]; red[(16 + g) * 256 + tid] = DV[db][g]; }
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { DK[db][g] += red[g * 256 + tid]; DV[db][g] += red[(16 + g) * 256 + tid]; }
+      }
+      __syncthreads();
+    }
+    if (grp == 1) return;
+  }
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) DK[db][g] *= p.scale;
+  const int kloc = wave * 32 + r;
+  if (slab >= 0) {
+    float* ws = p.dkv_ws + ((int64_t)slab * p.Hkv + kvh) * (2 * KT * 128) + (int64_t)kloc * 128;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = 32 * db + 8 * gq + 4 * h;
+        *reinterpret_cast<float4*>(ws + d) = make_float4(DK[db][4 * gq], DK[db][4 * gq + 1], DK[db][4 * gq + 2], DK[db][4 * gq + 3]);
+        *reinterpret_cast<float4*>(ws + KT * 128 + d) = make_float4(DV[db][4 * gq], DV[db][4 * gq + 1], DV[db][4 * gq + 2], DV[db][4 * gq + 3]);
+      }
+  } else if (kidx < p.Tk && p.accumulate == 2) {
+    // fp32 accumulation buffers (the grad-KV stack of the block-wise engine: hundreds of adds per row stay exact to fp32)
+    float* dkp = reinterpret_cast<float*>(p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+    float* dvp = reinterpret_cast<float*>(p.dv) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = 32 * db + 8 * gq + 4 * h;
+        float4 a = *reinterpret_cast<const float4*>(dkp + d), b = *reinterpret_cast<const float4*>(dvp + d);
+        a.x += DK[db][4 * gq]; a.y += DK[db][4 * gq + 1]; a.z += DK[db][4 * gq + 2]; a.w += DK[db][4 * gq + 3];
+        b.x += DV[db][4 * gq]; b.y += DV[db][4 * gq + 1]; b.z += DV[db][4 * gq + 2]; b.w += DV[db][4 * gq + 3];
+        *reinterpret_cast<float4*>(dkp + d) = a;
+        *reinterpret_cast<float4*>(dvp + d) = b;
+      }
+  } else if (kidx < p.Tk) {
+    e* dkp = reinterpret_cast<e*>(p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+    e* dvp = reinterpret_cast<e*>(p.dv) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d = 32 * db + 8 * gq + 4 * h;
+        v4 wk, wv;
+        if (p.accumulate) {
+          const v4 ok_ = *reinterpret_cast<const v4*>(dkp + d); const v4 ov_ = *reinterpret_cast<const v4*>(dvp + d);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { wk[j] = (e)(DK[db][4 * gq + j] + (float)ok_[j]); wv[j] = (e)(DV[db][4 * gq + j] + (float)ov_[j]); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { wk[j] = (e)DK[db][4 * gq + j]; wv[j] = (e)DV[db][4 * gq + j]; }
+        }
+        *reinterpret_cast<v4*>(dkp + d) = wk;
+        *reinterpret_cast<v4*>(dvp + d) = wv;
+      }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// dK/dV with ONE wave per SIMD (4 waves) and 64 keys per wave: wave = (key slot ks of 64 keys, query half grp of every
+// 64-row tile).  The 256 accumulators (dK, dV of 64 keys) fill the AGPR half of the 512-register file; K and V fragments
+// (pure MFMA B operands) live in LDS in fragment order.  Per tile a wave runs four MFMA phases of 16,
+//   A: S0,S1      B: dP0,dP1 | p = exp2(c*S - lse), pack P      C: dV0,dV1 | dS = p*dP', pack dS      D: dK0,dK1
+// so that all softmax VALU lies in the MFMA shadow of the SAME wave (there is no second wave on the SIMD to hide behind),
+// and every Q/dO fragment read from LDS (row-wise and transposed) feeds two MFMAs: 4.5 LDS cycles per MFMA against 7 in the
+// 8-wave kernel.  The tile body exists unmasked and masked so that each is one basic block for the scheduler.
+// -------------------------------------------------------------------------------------------------
+// VGPR-form MFMA from inline asm.  With a 512-register budget hipcc selects the AGPR form for EVERY builtin MFMA of the function
+// (all-or-nothing, SIMachineFunctionInfo::mayNeedAGPRs): S / dP would then sit in AGPRs next to the 256 dK/dV accumulators
+// (320 > 256: spills) and be copied out for the softmax.  S and dP therefore accumulate in VGPRs through these; the hazard
+// recognizer does not see them, so the consumer side carries its own wait states (mma_v_fence).
+template <int DT> __device__ __forceinline__ void mma_v(f32x16& acc, const typename Ty<DT>::v8& a, const typename Ty<DT>::v8& b) {
+  if constexpr (DT == DTA_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <int DT> __device__ __forceinline__ void mma_v0(f32x16& acc, const typename Ty<DT>::v8& a, const typename Ty<DT>::v8& b) {   // acc = a*b
+  if constexpr (DT == DTA_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b));
+}
+template <int DT> __device__ __forceinline__ void mma_vc(f32x16& acc, const typename Ty<DT>::v8& a, const typename Ty<DT>::v8& b, const f32x16& cin) {   // acc = a*b + cin
+  if constexpr (DT == DTA_BF16) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(cin));
+  else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(cin));
+}
+// single LDS-DMA instructions for bases that come from SALU arithmetic (no VALU-written SGPR: no s_nop 4), one per MFMA gap
+__device__ __forceinline__ void dma_x4(uint32_t off, const void* base, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void dma_x1(uint32_t off, const void* base, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(off), "s"(base), "s"(lds) : "memory");
+}
+typedef float f32x4a __attribute__((ext_vector_type(4), aligned(16)));
+template <int IMM> __device__ __forceinline__ void dma_x4i(uint32_t off, const void* base, uint32_t lds) {      // LDS target = lds + IMM
+  asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(off), "s"(base), "s"(lds), "n"(IMM) : "memory", "scc");
+}
+template <int DT> __device__ __forceinline__ uint32_t pack2(float a, float b) {                                   // {a, b} -> two 16-bit values, RNE
+  using e = typename Ty<DT>::e; typedef e e2 __attribute__((ext_vector_type(2)));
+  e2 t; t[0] = (e)a; t[1] = (e)b; return __builtin_bit_cast(uint32_t, t);
+}
+template <class V8> __device__ __forceinline__ V8 w4(const uint32_t (&w)[4]) { u32x4 t = {w[0], w[1], w[2], w[3]}; return __builtin_bit_cast(V8, t); }
+// an 8-pass XDL result may be read by VALU 11 wait states after the MFMA was issued (what hipcc pads to for the builtin form)
+__device__ __forceinline__ void mma_v_fence(f32x16& a, f32x16& b) { asm("s_nop 11" : "+v"(a), "+v"(b)); }
+constexpr int KV3_FRAGS = 2 * 32768;                                 // 2 key slots x {K: 2 blocks x 8 fragments x 1 KiB, V: same}
+constexpr int KV3_LDS = KV3_FRAGS + 2 * KV2_BUF + 16;
+
+template <int DT>
+__global__ __launch_bounds__(256) void tree_attn_bwd_dkv3_kernel(AttnParams p) {
+  using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
+  constexpr int KT = 128;
+  __shared__ __attribute__((aligned(16))) char smem_all[KV3_LDS];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, tid2 = tid & 127;
+  const int wave4 = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0..3
+  const int grp = wave4 >> 1, ks = wave4 & 1;
+  char* kfr = smem_all + ks * 32768 + lane * 16;                     // this lane's slice of the key slot's K fragments [block][s] (+16384: V)
+  char* smem = smem_all + KV3_FRAGS;                                 // the Q/dO buffers
+  const int bid = blockIdx.x;
+  const int kvh = bid % p.Hkv; const int unit = bid / p.Hkv;
+  const int kt = p.dkv_units ? p.dkv_units[4 * unit] : unit;
+  const int slab = p.dkv_units ? p.dkv_units[4 * unit + 3] : -1;
+  const int k0 = kt * KT;
+  const int q_hi = p.q_offset + p.Tq;
+  int kidx[2], se_l[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    kidx[b] = k0 + ks * 64 + 32 * b + r;
+    const int kc = kidx[b] < p.Tk ? kidx[b] : p.Tk - 1;
+    const int se = (kidx[b] < p.Tk) ? (p.subtree_end ? p.subtree_end[kidx[b]] : 0x7fffffff) : 0;
+    se_l[b] = se < q_hi ? se : q_hi;
+    if (grp == 0) {                                                  // half 0 stages the fragments both halves read
+      const e* kp = reinterpret_cast<const e*>(p.k) + (int64_t)kc * p.kv_st + (int64_t)kvh * p.kv_sh;
+      const e* vp = reinterpret_cast<const e*>(p.v) + (int64_t)kc * p.v_st + (int64_t)kvh * p.v_sh;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        *reinterpret_cast<v8*>(kfr + (8 * b + s) * 1024) = *reinterpret_cast<const v8*>(kp + 16 * s + 8 * h);
+        *reinterpret_cast<v8*>(kfr + 16384 + (8 * b + s) * 1024) = *reinterpret_cast<const v8*>(vp + 16 * s + 8 * h);
+      }
+    }
+  }
+  int* se_min_s = reinterpret_cast<int*>(smem_all + KV3_FRAGS + 2 * KV2_BUF);
+  { int mn = se_l[0] < se_l[1] ? se_l[0] : se_l[1];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mn, o); mn = t < mn ? t : mn; }
+    if (lane == 0 && grp == 0) se_min_s[ks] = mn; }
+  __syncthreads();
+  const int se_min = __builtin_amdgcn_readfirstlane(min(se_min_s[0], se_min_s[1]));
+
+  const FragOffs offs = frag_offsets(lane);
+  f32x16 DK[2][4], DV[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) { DK[b][db][g] = 0.f; DV[b][db][g] = 0.f; }
+
+  int qbeg, qend;
+  if (p.dkv_units) { qbeg = __builtin_amdgcn_readfirstlane(p.dkv_units[4 * unit + 1]); qend = __builtin_amdgcn_readfirstlane(p.dkv_units[4 * unit + 2]); }
+  else {
+    qbeg = k0 > p.q_offset ? k0 : p.q_offset;
+    qend = p.ktile_qend ? p.ktile_qend[kt] : q_hi; qend = qend < q_hi ? qend : q_hi;
+  }
+  const int ntile = qend > qbeg ? (qend - qbeg + 63) / 64 : 0;
+  const int total = ntile * p.group;
+  const float c = p.scale * LOG2E;
+
+  // tile DMA: 16 one-KiB pieces per image over 4 waves = 4 per wave per image (piece 4*wave4 + i: rows 16*wave4 + 4*i ..);
+  // lse / delta rows by 4-byte DMA from waves 0 / 1
+  uint32_t voff_q[4], voff_d[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row_ = 16 * wave4 + 4 * i + (lane >> 4);
+    voff_q[i] = dma_src_off(row_, row_, lane, p.q_st, sizeof(e));
+    voff_d[i] = dma_src_off(row_, row_, lane, p.o_st, sizeof(e));
+  }
+  const uint32_t lds_tiles = lds_addr(smem);
+  const int64_t q_step = 64 * p.q_st * (int64_t)sizeof(e), d_step = 64 * p.o_st * (int64_t)sizeof(e);
+  const int64_t q_wrap = p.q_sh * (int64_t)sizeof(e) - ntile * q_step, d_wrap = p.o_sh * (int64_t)sizeof(e) - ntile * d_step;
+  // scalar cursor of the NEXT tile to stage (byte offsets of its first row in q / dout, float offset of its row constants, row)
+  const int64_t q_first = ((int64_t)(kvh * p.group) * p.q_sh + (int64_t)(qbeg - p.q_offset) * p.q_st) * (int64_t)sizeof(e);
+  const int64_t d_first = ((int64_t)(kvh * p.group) * p.o_sh + (int64_t)(qbeg - p.q_offset) * p.o_st) * (int64_t)sizeof(e);
+  const int64_t c_first = (int64_t)(kvh * p.group) * p.Tq;
+  const int row_first = qbeg - p.q_offset;
+  int64_t q_cur = q_first, d_cur = d_first, c_cur = c_first;
+  int row_n = row_first, ti_n = 0;
+  // the ragged last tile of the tensor (rows beyond Tq: clamp the row per lane) can only be this unit's LAST tile: its per-lane
+  // offsets are loop invariant, and a piece selects between the two sets by a uniform flag
+  uint32_t rq[4], rd[4];
+  { const int row_l = row_first + 64 * (ntile - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ra = 16 * wave4 + 4 * i + (lane >> 4);
+      const int ca = row_l + ra < p.Tq ? ra : p.Tq - 1 - row_l;
+      rq[i] = dma_src_off(ca, ra, lane, p.q_st, sizeof(e)); rd[i] = dma_src_off(ca, ra, lane, p.o_st, sizeof(e)); } }
+  const float* const rowc = wave4 == 0 ? p.lse_r : p.delta;          // waves 0 / 1 stage lse[64] / delta[64]
+  // per-tile scalar setup of the staging: source bases, LDS targets of this wave's pieces, row-constant lane offset
+#define KV3_STAGE_SETUP(QOFF_, DOFF_, COFF_, ROW_, NB_)                                                    \
+  const bool ragged_ = (ROW_) + 64 > p.Tq;                                                                 \
+  const char* const qb_ = reinterpret_cast<const char*>(p.q) + (QOFF_);                                    \
+  const char* const db_ = reinterpret_cast<const char*>(p.dout) + (DOFF_);                                 \
+  const float* const cb_ = rowc + (COFF_);                                                                 \
+  const uint32_t nbw_ = (NB_) + wave4 * 4096, nbc_ = (NB_) + 2 * TILE_BYTES + wave4 * 256;                \
+  uint32_t qr4_; { int qr_ = (ROW_) + lane; qr_ = qr_ < p.Tq ? qr_ : p.Tq - 1; qr4_ = (uint32_t)qr_ * 4u; }
+  // piece K_: 0..3 Q image, 4..7 dO image, 8 row constants - three instructions each (s_add m0 / s_nop / DMA)
+#define KV3_PIECE(K_)                                                                                      \
+  { constexpr int k_ = (K_);                                                                               \
+    if (k_ < 4) dma_x4i<(k_ & 3) * 1024>(ragged_ ? rq[k_ & 3] : voff_q[k_ & 3], qb_, nbw_);                \
+    else if (k_ < 8) dma_x4i<TILE_BYTES + (k_ & 3) * 1024>(ragged_ ? rd[k_ & 3] : voff_d[k_ & 3], db_, nbw_); \
+    else if (wave4 < 2) dma_x1(qr4_, cb_, nbc_); }
+#define KV3_DMA_ADVANCE()                                                                                  \
+  { ++ti_n; row_n += 64; q_cur += q_step; d_cur += d_step;                                                 \
+    if (ti_n >= ntile) { ti_n = 0; row_n = row_first; q_cur += q_wrap; d_cur += d_wrap; c_cur += p.Tq; } }
+
+  // Loop-carried LDS byte addresses (relative to smem_all) of this lane's fragment reads in the CURRENT tile buffer; they move by
+  // +-KV2_BUF once per tile (17 v_add, in the last MFMA gaps) so that every read is <register> + <immediate> with a run-time buffer.
+  int arc[8], atc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { arc[j] = KV3_FRAGS + offs.row[j] + grp * (32 * 256); atc[j] = KV3_FRAGS + offs.tr[j] + grp * (32 * 256); }
+  int rcc = KV3_FRAGS + 2 * TILE_BYTES + (32 * grp + 4 * h) * 4;       // row constants: lse at +32*gq, -delta at +256+32*gq
+
+  // ONE straight-line tile body of 64 MFMA "gaps": every accumulator has a single definition per iteration, so the loop phis coalesce
+  // in place (unrolled over buffers / mask variants, the 256 AGPR accumulators - no spare AGPR - were shuffled through scratch).
+  // A gap = one MFMA + the instructions that issue in its 32-cycle shadow, pinned by sched_barrier: with one wave per SIMD the issue
+  // order IS the schedule (MI355X_MICROARCH: about 24 cycles of fillers hide per gap; fma/mul/ds_read 4, exp 8, cvt_pk 4.5).
+  //   A   0-15  S0,S1 = Q K^T            | operand loads three steps ahead; the next tile's 9 DMA pieces; row constants
+  //   B  16-31  dP0',dP1' = dO V^T-delta | p = exp2(c S - lse) rows 0-7, one element per gap; their packs
+  //   C0 32-39  dV += dO^T P   (k 0-15)  | p rows 8-15 (block 0); dS = p dP' rows 0-7 and their packs
+  //   D0 40-47  dK += Q^T dS   (k 0-15)  | p rows 8-15 (block 1); packs of P rows 8-15
+  //   C1 48-55  dV += dO^T P   (k 16-31) | dS rows 8-15 and their packs
+  //   D1 56-63  dK += Q^T dS   (k 16-31) | the 17 address updates
+  // Hazards the asm MFMAs carry themselves (hipcc's recognizer does not see them): an 8-pass result may be read by VALU 11 issue
+  // slots after the MFMA - S0 (last MFMA gap 14) is first read in gap 16, S1 (15) in gap 24, dP0' (30) in 33, dP1' (31) in 37.
+#define KV3_LDA(T_) { const int t_ = (T_); fa[t_ % KV3_NBUF] = *reinterpret_cast<const v8*>(smem_all + arc[t_ & 7] + (t_ >> 3) * TILE_BYTES); \
+                      fb[t_ % KV3_NBUF] = *reinterpret_cast<const v8*>(kfr + (t_ >> 3) * 16384 + (t_ & 7) * 1024); }
+#define KV3_LDB(T_) { const int t_ = (T_); fc[t_ % KV3_NBUF] = *reinterpret_cast<const v8*>(kfr + (t_ >> 3) * 16384 + (8 + (t_ & 7)) * 1024); }
+  // element E_ (0..31): 0-7 block 0 rows 0-7, 8-15 block 1 rows 0-7, 16-23 block 0 rows 8-15, 24-31 block 1 rows 8-15
+#define KV3_ELEM(E_) if (KV3_T_VALU) { const int e_ = (E_), g_ = (e_ & 7) + ((e_ >> 4) << 3);                              \
+    if (((e_ >> 3) & 1) == 0) S0[g_] = fast_exp2(__builtin_fmaf(S0[g_], c, -nl[g_])); else S1[g_] = fast_exp2(__builtin_fmaf(S1[g_], c, -nl[g_])); }
+#define KV3_MUL(E_) if (KV3_T_VALU) { const int e_ = (E_), g_ = (e_ & 7) + ((e_ >> 4) << 3);                               \
+    if (((e_ >> 3) & 1) == 0) { float t_ = DP0[g_] * S0[g_]; asm("" : "+v"(t_)); DP0[g_] = t_; }            \
+    else { float t_ = DP1[g_] * S1[g_]; asm("" : "+v"(t_)); DP1[g_] = t_; } }     /* the empty asm keeps hipcc from SLP-packing these into v_pk_mul_f32 */
+  // pack rows 2*R2_, 2*R2_+1 (R2_ 0..7) of key block B_ of P / dS into their dword of the MFMA B-operand fragments
+#define KV3_CVTP(B_, R2_) if (KV3_T_VALU) { const int r_ = (R2_); if ((B_) == 0) pw0[r_ >> 2][r_ & 3] = pack2<DT>(S0[2 * r_], S0[2 * r_ + 1]); else pw1[r_ >> 2][r_ & 3] = pack2<DT>(S1[2 * r_], S1[2 * r_ + 1]); }
+#define KV3_CVTS(B_, R2_) if (KV3_T_VALU) { const int r_ = (R2_); if ((B_) == 0) sw0[r_ >> 2][r_ & 3] = pack2<DT>(DP0[2 * r_], DP0[2 * r_ + 1]); else sw1[r_ >> 2][r_ & 3] = pack2<DT>(DP1[2 * r_], DP1[2 * r_ + 1]); }
+  // transposed operand of C/D pair W_ (0..15, issue order): 0-3 dO^T k 0-15, 4-7 Q^T k 0-15, 8-11 dO^T k 16-31, 12-15 Q^T k 16-31
+#define KV3_TR(W_) { const int w_ = (W_), s2_ = w_ >> 3, db_i = w_ & 3, img_ = ((w_ >> 2) & 1) ? 0 : TILE_BYTES;                      \
+    tf[w_ % KV3_NTR] = tr_pair<v8>(smem_all + atc[db_i] + img_ + 4096 * s2_, smem_all + atc[4 + db_i] + img_ + 4096 * s2_); }
+#define KV3_GAP(GP_) { constexpr int gp = (GP_); \
+        const int ph = gp >> 4, t = (gp & 15) >> 1, odd = gp & 1; \
+        /* ---- the MFMA of this gap */ \
+        if (ph == 0) { \
+          const int j = t % KV3_NBUF; \
+          if (gp == 0) { if (full) mma_v0<DT>(S0, fa[j], fb[j]); else mma_v<DT>(S0, fa[j], fb[j]); } \
+          else if (gp == 1) { if (full) mma_v0<DT>(S1, fa[j], fc[j]); else mma_v<DT>(S1, fa[j], fc[j]); } \
+          else if (!odd) mma_v<DT>(S0, fa[j], fb[j]); else mma_v<DT>(S1, fa[j], fc[j]); \
+        } else if (ph == 1) { \
+          const int j = (8 + t) % KV3_NBUF; \
+          if (gp == 16) mma_vc<DT>(DP0, fa[j], fb[j], DI); \
+          else if (gp == 17) mma_vc<DT>(DP1, fa[j], fc[j], DI); \
+          else if (!odd) mma_v<DT>(DP0, fa[j], fb[j]); else mma_v<DT>(DP1, fa[j], fc[j]); \
+        } else { \
+          const int w = (gp - 32) >> 1, s2 = w >> 3, db = w & 3, j = w % KV3_NTR; \
+          if (((w >> 2) & 1) == 0) { if (!odd) DV[0][db] = T::mma(tf[j], w4<v8>(pw0[s2]), DV[0][db]); else DV[1][db] = T::mma(tf[j], w4<v8>(pw1[s2]), DV[1][db]); } \
+          else { if (!odd) DK[0][db] = T::mma(tf[j], w4<v8>(sw0[s2]), DK[0][db]); else DK[1][db] = T::mma(tf[j], w4<v8>(sw1[s2]), DK[1][db]); } \
+        } \
+        /* ---- fillers */ \
+        /* operands of step T (gaps 2T, 2T+1) go into the buffer step T-NBUF freed: fa,fb in gap 2(T-NBUF)+1, fc in the gap after */ \
+        if (gp >= 1 && gp <= 2 * (15 - KV3_NBUF) + 2 && KV3_T_LD) { \
+          if (gp & 1) { KV3_LDA(((gp - 1) >> 1) + KV3_NBUF) } else { KV3_LDB(((gp - 2) >> 1) + KV3_NBUF) } \
+        } \
+        if (gp >= 3 && gp <= 11 && KV3_TIMING_DMA) KV3_PIECE(gp - 3) \
+        if (gp == 12) { \
+_Pragma("unroll") \
+          for (int gq = 0; gq < 4; ++gq) { \
+            const f32x4a d4 = *reinterpret_cast<const f32x4a*>(smem_all + rcc + 256 + 32 * gq); \
+            DI[4 * gq] = d4.x; DI[4 * gq + 1] = d4.y; DI[4 * gq + 2] = d4.z; DI[4 * gq + 3] = d4.w; \
+          } \
+        } \
+        if (gp == 13) { \
+_Pragma("unroll") \
+          for (int gq = 0; gq < 4; ++gq) { \
+            const f32x4a l4 = *reinterpret_cast<const f32x4a*>(smem_all + rcc + 32 * gq); \
+            nl[4 * gq] = l4.x; nl[4 * gq + 1] = l4.y; nl[4 * gq + 2] = l4.z; nl[4 * gq + 3] = l4.w; \
+          } \
+        } \
+        if (gp == 14 && has_next) KV3_DMA_ADVANCE() \
+        /* p = exp2(c S - lse): 20 elements in B (1,1,1,2 per gap), 4 in C0 (odd gaps), 8 in D0 */ \
+        if (gp >= 16 && gp <= 31) { constexpr int q4 = (gp - 16) >> 2, r4 = (gp - 16) & 3; KV3_ELEM(5 * q4 + r4) if (r4 == 3) KV3_ELEM(5 * q4 + 4) } \
+        if (gp >= 33 && gp <= 39 && (gp & 1)) KV3_ELEM(20 + ((gp - 33) >> 1)) \
+        if (gp >= 40 && gp <= 47) KV3_ELEM(24 + gp - 40) \
+        /* packs of P (block, row pair): as soon as both rows exist, one or two per gap */ \
+        if (gp == 18) KV3_CVTP(0, 0) if (gp == 20) KV3_CVTP(0, 1) if (gp == 21) KV3_CVTP(0, 2) if (gp == 24) KV3_CVTP(0, 3) \
+        if (gp == 25) KV3_CVTP(1, 0) if (gp == 26) KV3_CVTP(1, 1) if (gp == 28) KV3_CVTP(1, 2) if (gp == 29) KV3_CVTP(1, 3) \
+        if (gp == 32) KV3_CVTP(0, 4) if (gp == 33) KV3_CVTP(0, 5) if (gp == 40) KV3_CVTP(0, 6) if (gp == 41) KV3_CVTP(0, 7) \
+        if (gp == 42) KV3_CVTP(1, 4) if (gp == 44) KV3_CVTP(1, 5) if (gp == 46) KV3_CVTP(1, 6) if (gp == 48) KV3_CVTP(1, 7) \
+        /* transposed operands: pair W (gaps 32+2W, 33+2W) goes into the buffer pair W-NTR freed, the first NTR-1 in the last B gaps */ \
+        if (gp >= 32 - (KV3_NTR - 1) - 1 && gp <= 30) KV3_TR(gp - (32 - (KV3_NTR - 1) - 1)) \
+        if (gp >= 32 && gp <= 32 + 2 * (15 - (KV3_NTR - 1)) && !(gp & 1) && (KV3_T_TR || gp == 32)) KV3_TR(((gp - 32) >> 1) + KV3_NTR - 1) \
+        /* dS = p dP' rows 0-7 in C0 (block 0 from gap 33, block 1 from gap 36: the dP' hazard), rows 8-15 in C1; their packs */ \
+        if (gp == 33) { KV3_MUL(0) KV3_MUL(1) } \
+        if (gp == 34) { KV3_MUL(2) KV3_MUL(3) KV3_MUL(4) KV3_CVTS(0, 0) } \
+        if (gp == 35) { KV3_MUL(5) KV3_MUL(6) KV3_MUL(7) KV3_CVTS(0, 1) } \
+        if (gp == 36) { KV3_MUL(8) KV3_MUL(9) KV3_MUL(10) KV3_CVTS(0, 2) KV3_CVTS(0, 3) } \
+        if (gp == 37) { KV3_MUL(11) KV3_MUL(12) KV3_CVTS(1, 0) } \
+        if (gp == 38) { KV3_MUL(13) KV3_MUL(14) KV3_MUL(15) KV3_CVTS(1, 1) } \
+        if (gp == 39) { KV3_CVTS(1, 2) KV3_CVTS(1, 3) } \
+        if (gp >= 48 && gp <= 55) { KV3_MUL(16 + 2 * (gp - 48)) KV3_MUL(16 + 2 * (gp - 48) + 1) } \
+        if (gp >= 49 && gp <= 52) KV3_CVTS(0, 4 + gp - 49) \
+        if (gp >= 53 && gp <= 56) KV3_CVTS(1, 4 + gp - 53) \
+        if (gp >= 57) {                                              /* next tile's addresses: arc/rcc were last used in gap 25, atc in gap 58 */ \
+          const int dlt = cur ? -KV2_BUF : KV2_BUF; \
+          if (gp <= 60) { arc[2 * (gp - 57)] += dlt; arc[2 * (gp - 57) + 1] += dlt; if (gp == 60) rcc += dlt; } \
+          else if (gp == 61) { atc[0] += dlt; atc[1] += dlt; atc[2] += dlt; } \
+          else if (gp == 62) { atc[3] += dlt; atc[4] += dlt; atc[5] += dlt; } \
+          else { atc[6] += dlt; atc[7] += dlt; } \
+        } \
+        __builtin_amdgcn_sched_barrier(0); \
+      }
+#ifndef KV3_TIMING_DMA
+#define KV3_TIMING_DMA 1
+#endif
+#ifndef KV3_T_VALU
+#define KV3_T_VALU 1          /* timing-only ablations (results wrong when 0) */
+#define KV3_T_LD 1
+#define KV3_T_TR 1
+#endif
+#ifndef KV3_NBUF
+#define KV3_NBUF 3            /* A/B operand buffers: loads run NBUF steps (2*NBUF gaps) ahead of their MFMAs */
+#define KV3_NTR 3             /* transposed-operand buffers */
+#endif
+  {
+    int ti_c = 0;
+    if (total > 0) {
+      { KV3_STAGE_SETUP(q_cur, d_cur, c_cur, row_n, lds_tiles)
+        KV3_PIECE(0) KV3_PIECE(1) KV3_PIECE(2) KV3_PIECE(3) KV3_PIECE(4) KV3_PIECE(5) KV3_PIECE(6) KV3_PIECE(7) KV3_PIECE(8) }
+      KV3_DMA_ADVANCE()
+    }
+    DMA_WAIT(); __syncthreads();
+    int cur = 0;
+    for (int idx = 0; idx < total; ++idx) {
+      const int ti = ti_c;
+      ti_c += 1;
+      if (ti_c >= ntile) ti_c = 0;
+      // the buffer the next tile lands in was last read before the previous barrier.  On the last tile of the unit the pieces
+      // re-stage the unit's FIRST tile (valid rows, nobody reads it): no branch around the nine DMA gaps
+      const bool has_next = idx + 1 < total;
+      const int row_sel = has_next ? row_n : row_first;
+      KV3_STAGE_SETUP(has_next ? q_cur : q_first, has_next ? d_cur : d_first, has_next ? c_cur : c_first, row_sel, lds_tiles + (uint32_t)(1 - cur) * KV2_BUF)
+      const int qi0 = qbeg + 64 * ti + 32 * grp;                       /* packed index of this half's first row */
+      const bool full = (qbeg + 64 * ti >= k0 + KT - 1) && (qbeg + 64 * ti + 63 < se_min);   /* workgroup-uniform */
+      f32x16 S0, S1, DP0, DP1, DI;
+      float nl[16];
+      v8 fa[KV3_NBUF], fb[KV3_NBUF], fc[KV3_NBUF], tf[KV3_NTR];
+      uint32_t pw0[2][4], pw1[2][4], sw0[2][4], sw1[2][4];
+      if (!KV3_T_VALU) { for (int a_ = 0; a_ < 2; ++a_) for (int b_ = 0; b_ < 4; ++b_) { pw0[a_][b_] = 0x3c003c00u; pw1[a_][b_] = 0x3c003c00u; sw0[a_][b_] = 0x3c003c00u; sw1[a_][b_] = 0x3c003c00u; } }
+      KV3_LDA(0) KV3_LDB(0) KV3_LDA(1) KV3_LDB(1) KV3_LDA(2) KV3_LDB(2)
+      if (KV3_NBUF > 3) { KV3_LDA(3) KV3_LDB(3) }
+      if (!full) {             /* masked tile (rare): the mask enters as the initial S accumulator, 0 or -1e30 -> p = 0 */
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int qi = qi0 + 8 * (g >> 2) + 4 * h + (g & 3);
+          S0[g] = ((kidx[0] <= qi) && (qi < se_l[0])) ? 0.f : -1e30f; S1[g] = ((kidx[1] <= qi) && (qi < se_l[1])) ? 0.f : -1e30f;
+        }
+      }
+      KV3_GAP(0) KV3_GAP(1) KV3_GAP(2) KV3_GAP(3) KV3_GAP(4) KV3_GAP(5) KV3_GAP(6) KV3_GAP(7)
+      KV3_GAP(8) KV3_GAP(9) KV3_GAP(10) KV3_GAP(11) KV3_GAP(12) KV3_GAP(13) KV3_GAP(14) KV3_GAP(15)
+      KV3_GAP(16) KV3_GAP(17) KV3_GAP(18) KV3_GAP(19) KV3_GAP(20) KV3_GAP(21) KV3_GAP(22) KV3_GAP(23)
+      KV3_GAP(24) KV3_GAP(25) KV3_GAP(26) KV3_GAP(27) KV3_GAP(28) KV3_GAP(29) KV3_GAP(30) KV3_GAP(31)
+      KV3_GAP(32) KV3_GAP(33) KV3_GAP(34) KV3_GAP(35) KV3_GAP(36) KV3_GAP(37) KV3_GAP(38) KV3_GAP(39)
+      KV3_GAP(40) KV3_GAP(41) KV3_GAP(42) KV3_GAP(43) KV3_GAP(44) KV3_GAP(45) KV3_GAP(46) KV3_GAP(47)
+      KV3_GAP(48) KV3_GAP(49) KV3_GAP(50) KV3_GAP(51) KV3_GAP(52) KV3_GAP(53) KV3_GAP(54) KV3_GAP(55)
+      KV3_GAP(56) KV3_GAP(57) KV3_GAP(58) KV3_GAP(59) KV3_GAP(60) KV3_GAP(61) KV3_GAP(62) KV3_GAP(63)
+#ifndef KV3_TIMING_NOBARRIER
+      DMA_WAIT(); __syncthreads();
+#endif
+      cur ^= 1;
+    }
+  }
+#undef KV3_GAP
+#undef KV3_TR
+#undef KV3_CVTS
+#undef KV3_CVTP
+#undef KV3_MUL
+#undef KV3_ELEM
+#undef KV3_LDB
+#undef KV3_LDA
+#undef KV3_DMA_ADVANCE
+#undef KV3_PIECE
+#undef KV3_STAGE_SETUP
+  {
+    // query half 1 hands its partial sums to half 0 through LDS, 32 accumulators (one d-block of dK and dV) at a time
+    float* red = reinterpret_cast<float*>(smem_all);
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        if (grp == 1) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) { red[g * 128 + tid2] = DK[b][db][g]; red[(16 + g) * 128 + tid2] = DV[b][db][g]; }
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+          for (int g = 0; g < 16; ++g) { DK[b][db][g] += red[g * 128 + tid2]; DV[b][db][g] += red[(16 + g) * 128 + tid2]; }
+        }
+        __syncthreads();
+      }
+    if (grp == 1) return;
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) DK[b][db][g] *= p.scale;
+    const int kloc = ks * 64 + 32 * b + r;
+    if (slab >= 0) {
+      float* ws = p.dkv_ws + ((int64_t)slab * p.Hkv + kvh) * (2 * KT * 128) + (int64_t)kloc * 128;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int d = 32 * db + 8 * gq + 4 * h;
+          *reinterpret_cast<float4*>(ws + d) = make_float4(DK[b][db][4 * gq], DK[b][db][4 * gq + 1], DK[b][db][4 * gq + 2], DK[b][db][4 * gq + 3]);
+          *reinterpret_cast<float4*>(ws + KT * 128 + d) = make_float4(DV[b][db][4 * gq], DV[b][db][4 * gq + 1], DV[b][db][4 * gq + 2], DV[b][db][4 * gq + 3]);
+        }
+    } else if (kidx[b] < p.Tk && p.accumulate == 2) {
+      float* dkp = reinterpret_cast<float*>(p.dk) + (int64_t)kidx[b] * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+      float* dvp = reinterpret_cast<float*>(p.dv) + (int64_t)kidx[b] * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int d = 32 * db + 8 * gq + 4 * h;
+          float4 a = *reinterpret_cast<const float4*>(dkp + d), bb = *reinterpret_cast<const float4*>(dvp + d);
+          a.x += DK[b][db][4 * gq]; a.y += DK[b][db][4 * gq + 1]; a.z += DK[b][db][4 * gq + 2]; a.w += DK[b][db][4 * gq + 3];
+          bb.x += DV[b][db][4 * gq]; bb.y += DV[b][db][4 * gq + 1]; bb.z += DV[b][db][4 * gq + 2]; bb.w += DV[b][db][4 * gq + 3];
+          *reinterpret_cast<float4*>(dkp + d) = a;
+          *reinterpret_cast<float4*>(dvp + d) = bb;
+        }
+    } else if (kidx[b] < p.Tk) {
+      e* dkp = reinterpret_cast<e*>(p.dk) + (int64_t)kidx[b] * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+      e* dvp = reinterpret_cast<e*>(p.dv) + (int64_t)kidx[b] * p.dkv_st + (int64_t)kvh * p.dkv_sh;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int d = 32 * db + 8 * gq + 4 * h;
+          v4 wk, wv;
+          if (p.accumulate) {
+            const v4 ok_ = *reinterpret_cast<const v4*>(dkp + d); const v4 ov_ = *reinterpret_cast<const v4*>(dvp + d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wk[j] = (e)(DK[b][db][4 * gq + j] + (float)ok_[j]); wv[j] = (e)(DV[b][db][4 * gq + j] + (float)ov_[j]); }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wk[j] = (e)DK[b][db][4 * gq + j]; wv[j] = (e)DV[b][db][4 * gq + j]; }
+          }
+          *reinterpret_cast<v4*>(dkp + d) = wk;
+          *reinterpret_cast<v4*>(dvp + d) = wv;
+        }
+    }
+  }
+}
+
+// Sums the fp32 slabs of every split key tile in a fixed order and writes dK/dV (bitwise reproducible).
+// dkv_splits[s] = {key tile, first slab, number of slabs, 0}.
+constexpr int FIN_SPLIT = 8;          // blockIdx.y: each (split key tile, kv head) is summed by 8 workgroups — the sums are load-latency bound
+template <int DT>
+__global__ __launch_bounds__(256) void tree_attn_bwd_dkv_finalize_kernel(AttnParams p) {
+  using e = typename Ty<DT>::e; using v4 = typename Ty<DT>::v4;
+  const int KT = p.ktile;
+  const int kvh = blockIdx.x % p.Hkv, sp = blockIdx.x / p.Hkv;
+  const int kt = p.dkv_splits[4 * sp], first = p.dkv_splits[4 * sp + 1], n = p.dkv_splits[4 * sp + 2];
+  const int per = 2 * KT * 32 / FIN_SPLIT;                                // float4 indices per workgroup
+  const float* ws0 = p.dkv_ws + ((int64_t)first * p.Hkv + kvh) * (2 * KT * 128);
+  const int64_t slab_st = (int64_t)p.Hkv * (2 * KT * 128);
+  for (int i = blockIdx.y * per + threadIdx.x; i < (blockIdx.y + 1) * per; i += 256) {   // float4 index inside a slab
+    const int which = i / (KT * 32), rem = i - which * KT * 32;
+    const int key = rem >> 5, d = (rem & 31) << 2;
+    const int kidx = kt * KT + key;
+    if (kidx >= p.Tk) continue;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j = 0;
+    for (; j + 4 <= n; j += 4) {                                          // four loads in flight, summed in slab order
+      const float4 a0 = *reinterpret_cast<const float4*>(ws0 + (j + 0) * slab_st + (int64_t)i * 4);
+      const float4 a1 = *reinterpret_cast<const float4*>(ws0 + (j + 1) * slab_st + (int64_t)i * 4);
+      const float4 a2 = *reinterpret_cast<const float4*>(ws0 + (j + 2) * slab_st + (int64_t)i * 4);
+      const float4 a3 = *reinterpret_cast<const float4*>(ws0 + (j + 3) * slab_st + (int64_t)i * 4);
+      acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+      acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w;
+      acc.x += a2.x; acc.y += a2.y; acc.z += a2.z; acc.w += a2.w;
+      acc.x += a3.x; acc.y += a3.y; acc.z += a3.z; acc.w += a3.w;
+    }
+    for (; j < n; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(ws0 + j * slab_st + (int64_t)i * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (p.accumulate == 2) {
+      float* outf = reinterpret_cast<float*>(which ? p.dv : p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh + d;
+      float4 o = *reinterpret_cast<const float4*>(outf);
+      o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+      *reinterpret_cast<float4*>(outf) = o;
+      continue;
+    }
+    e* out = reinterpret_cast<e*>(which ? p.dv : p.dk) + (int64_t)kidx * p.dkv_st + (int64_t)kvh * p.dkv_sh + d;
+    if (p.accumulate) { const v4 o = *reinterpret_cast<const v4*>(out); acc.x += (float)o[0]; acc.y += (float)o[1]; acc.z += (float)o[2]; acc.w += (float)o[3]; }
+    v4 w; w[0] = (e)acc.x; w[1] = (e)acc.y; w[2] = (e)acc.z; w[3] = (e)acc.w;
+    *reinterpret_cast<v4*>(out) = w;
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v, void* out, float* lse,
+                                    const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
+                                    int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                                    int64_t q_st, int64_t q_sh, int64_t kv_st, int64_t kv_sh, int64_t v_st, int64_t v_sh, int64_t o_st, int64_t o_sh,
+                                    float scale, int32_t dtype, void* stream) {
+  if (!q || !k || !v || !out || !lse || Tq <= 0 || Tk <= 0 || Hq <= 0 || Hkv <= 0 || q_offset < 0) return DTA_EINVAL;
+  if ((runs == nullptr) != (run_ptr == nullptr)) return DTA_EINVAL;
+  if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16)) return DTA_EUNSUPPORTED;
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || (q_st | q_sh | kv_st | kv_sh | v_st | v_sh | o_st | o_sh) % 8 != 0) return DTA_EALIGN;
+  // the tile DMA addresses a 64-row tile as scalar base + 32-bit lane offset: token strides must keep 64 rows inside 4 GiB
+  if (kv_st < 0 || v_st < 0 || kv_st > (1 << 24) || v_st > (1 << 24)) return DTA_EUNSUPPORTED;
+  AttnParams p{};
+  p.q = q; p.k = k; p.v = v; p.out = out; p.lse_w = lse; p.subtree_end = subtree_end; p.run_ptr = run_ptr; p.runs = runs;
+  p.Tq = Tq; p.Tk = Tk; p.q_offset = q_offset; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
+  p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.v_st = v_st; p.v_sh = v_sh; p.o_st = o_st; p.o_sh = o_sh; p.scale = scale;
+  const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DTA_REFUSE_IF_PRIOR_ERROR();
+  if (p.group % 2 == 0) {      // two query heads of a kv group share the staged K/V tiles
+    dim3 grid(nqt * Hq / 2), block(512);
+    if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_BF16, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_F16, 2>), grid, block, 0, st, p);
+  } else {
+    dim3 grid(nqt * Hq), block(256);
+    if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_BF16, 1>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_F16, 1>), grid, block, 0, st, p);
+  }
+  return DTA_LAUNCH_STATUS();
+}
+
+extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                                    const float* lse, float* delta, void* dq, void* dk, void* dv,
+                                    const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
+                                    const int32_t* ktile_qend,
+                                    int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                                    int64_t q_st, int64_t q_sh, int64_t kv_st, int64_t kv_sh, int64_t v_st, int64_t v_sh, int64_t o_st, int64_t o_sh,
+                                    int64_t dq_st, int64_t dq_sh, int64_t dkv_st, int64_t dkv_sh,
+                                    float scale, int32_t dtype, int32_t accumulate, int32_t which,
+                                    const int32_t* dkv_units, int32_t n_units, const int32_t* dkv_splits, int32_t n_splits, float* dkv_ws,
+                                    void* stream) {
+  if (!q || !k || !v || !out || !dout || !lse || !delta || !dq || !dk || !dv || Tq <= 0 || Tk <= 0 || Hq <= 0 || Hkv <= 0 || q_offset < 0) return DTA_EINVAL;
+  if ((runs == nullptr) != (run_ptr == nullptr)) return DTA_EINVAL;
+  if (dkv_units && (n_units <= 0 || n_splits < 0 || (n_splits > 0 && (!dkv_splits || !dkv_ws)))) return DTA_EINVAL;
+  if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16) || accumulate < 0 || accumulate > 2) return DTA_EUNSUPPORTED;
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) ||
+      (q_st | q_sh | kv_st | kv_sh | v_st | v_sh | o_st | o_sh | dq_st | dq_sh | dkv_st | dkv_sh) % 8 != 0) return DTA_EALIGN;
+  if (q_st < 0 || o_st < 0 || q_st > (1 << 24) || o_st > (1 << 24)) return DTA_EUNSUPPORTED;   // 64-row tile = scalar base + 32-bit lane offset
+  AttnParams p{};
+  p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse_r = lse; p.delta = delta; p.dq = dq; p.dk = dk; p.dv = dv;
+  p.subtree_end = subtree_end; p.run_ptr = run_ptr; p.runs = runs; p.ktile_qend = ktile_qend;
+  p.dkv_units = dkv_units; p.dkv_splits = dkv_splits; p.dkv_ws = dkv_ws;
+  p.Tq = Tq; p.Tk = Tk; p.q_offset = q_offset; p.Hq = Hq; p.Hkv = Hkv; p.group = Hq / Hkv;
+  p.q_st = q_st; p.q_sh = q_sh; p.kv_st = kv_st; p.kv_sh = kv_sh; p.v_st = v_st; p.v_sh = v_sh; p.o_st = o_st; p.o_sh = o_sh;
+  p.dq_st = dq_st; p.dq_sh = dq_sh; p.dkv_st = dkv_st; p.dkv_sh = dkv_sh; p.scale = scale; p.accumulate = accumulate;
+  const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
+  p.ktile = DTA_KTILE;
+  const int nkt = (Tk + p.ktile - 1) / p.ktile;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DTA_REFUSE_IF_PRIOR_ERROR();
+  if ((which & 7) == 0) return DTA_EINVAL;
+  const bool fin = ((which & 2) && !(which & 8)) || (which & 4);     // slab finalize: with the dK/dV launch unless bit3, or alone (bit2)
+  const int ndkv = dkv_units ? n_units : nkt;
+  const bool pair = p.group % 2 == 0;
+  const dim3 gq(pair ? nqt * Hq / 2 : nqt * Hq), bq(pair ? 512 : 256);
+  if (dtype == DTA_BF16) {
+    if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 1>), gq, bq, 0, st, p); }
+#ifdef DTA_DKV3
+    if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv3_kernel<DTA_BF16>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
+#else
+    if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv2_kernel<DTA_BF16>), dim3(ndkv * Hkv), dim3(512), 0, st, p);
+#endif
+    if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_BF16>, dim3(n_splits * Hkv, FIN_SPLIT), dim3(256), 0, st, p);
+  } else {
+    if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 1>), gq, bq, 0, st, p); }
+#ifdef DTA_DKV3
+    if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv3_kernel<DTA_F16>), dim3(ndkv * Hkv), dim3(256), 0, st, p);
+#else
+    if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv2_kernel<DTA_F16>), dim3(ndkv * Hkv), dim3(512), 0, st, p);
+#endif
+    if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_F16>, dim3(n_splits * Hkv, FIN_SPLIT), dim3(256), 0, st, p);
+  }
+  return DTA_LAUNCH_STATUS();
+}
+
+// Token-major convenience forms declared in dta.h: head stride = 128 elements.
+extern "C" int dta_tree_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+                                 const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
+                                 int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                                 int64_t q_stride_t, int64_t kv_stride_t, int64_t o_stride_t,
+                                 float scale, int32_t dtype, void* stream) {
+  return dta_tree_attn_fwd_ex(q, k, v, out, lse, subtree_end, run_ptr, runs, Tq, Tk, q_offset, Hq, Hkv, head_dim,
+                              q_stride_t, 128, kv_stride_t, 128, kv_stride_t, 128, o_stride_t, 128, scale, dtype, stream);
+}
+
+extern "C" int dta_tree_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                                 const float* lse, float* delta, void* dq, void* dk, void* dv,
+                                 const int32_t* subtree_end, const int32_t* run_ptr, const int32_t* runs,
+                                 const int32_t* ktile_qend,
+                                 int32_t Tq, int32_t Tk, int32_t q_offset, int32_t Hq, int32_t Hkv, int32_t head_dim,
+                                 int64_t q_stride_t, int64_t kv_stride_t, int64_t o_stride_t,
+                                 int64_t dq_stride_t, int64_t dkv_stride_t,
+                                 float scale, int32_t dtype, int32_t accumulate, void* stream) {
+  return dta_tree_attn_bwd_ex(q, k, v, out, dout, lse, delta, dq, dk, dv, subtree_end, run_ptr, runs, ktile_qend,
+                              Tq, Tk, q_offset, Hq, Hkv, head_dim, q_stride_t, 128, kv_stride_t, 128, kv_stride_t, 128, o_stride_t, 128,
+                              dq_stride_t, 128, dkv_stride_t, 128, scale, dtype, accumulate, 3, nullptr, 0, nullptr, 0, nullptr, stream);
+}
