@@ -380,6 +380,9 @@ def main():
         "roofline": {"bound": "mfma", "kernel": DKV_KERNEL, "achieved": dkv_tf, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": dkv_tf / PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dkv_ms,
                      "flops_per_pair_per_layer": 8 * Hq * D, "pairs_per_step": pairs_r / max(steps, 1),
+                     "sustained_mfma_ceiling": {"value": 1729.0, "unit": "TFLOP/s", "frac_of_it": dkv_tf / 1729.0,
+                                                "source": "profiles/r2_mfma_dvfs_probe.json: a loop of nothing but v_mfma_f32_32x32x16_bf16 on random operands, two waves per SIMD "
+                                                          "(the chip lowers its clock under MFMA load; 2 455 on zeros) - `peak` stays the nominal 2.5 PFLOP/s"},
                      "measured_in": "a repeat of the timed steps with HIP events around every launch (not inside `value`'s timed region)",
                      "ms_per_step_with_timers": wall_r / steps * 1e3, "timer_overhead_frac": wall_r / wall - 1.0,
                      "other_kernels": {"tree_attn_fwd_kernel": {"bound": "mfma", "achieved": fwd_tf, "frac": fwd_tf / PEAK_TFLOPS, "avg_launch_ms": fwd_ms, "flops_per_pair_per_layer": 4 * Hq * D},
