@@ -433,7 +433,11 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
     for (int g = 0; g < 16; ++g) DQ[db][g] = 0.f;
   const float c = p.scale * LOG2E;
 
-  const float delta_s = delta * p.scale;
+  // dP starts at -delta (this lane's query row) instead of 0: dS/scale = p * dP' costs one multiply per element, and the softmax
+  // scale goes onto dQ once, in the epilogue (as the dK/dV kernel does for dK)
+  f32x16 DI;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) DI[g] = -delta;
   if (any) {
     int ck0 = it.k0, ckend = it.kend; bool cmask = it.masked();
     DTA_KV_DMA(smem, it.k0, NW)
@@ -450,13 +454,13 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
       for (int kb = 0; kb < 2; ++kb) {
         f32x16 X, DP;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) { X[g] = 0.f; DP[g] = 0.f; }
+        for (int g = 0; g < 16; ++g) X[g] = 0.f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
           X = T::mma(row_frag<v8>(Ks, 32 * kb + r, 2 * s + h), qf[s], X);
-          DP = T::mma(row_frag<v8>(Vs, 32 * kb + r, 2 * s + h), dof[s], DP);
+          DP = T::mma(row_frag<v8>(Vs, 32 * kb + r, 2 * s + h), dof[s], s == 0 ? DI : DP);
         }
-        // dS^T = P ∘ (dP·scale − delta·scale); the interval mask only on tiles of runs flagged partial
+        // dS^T / scale = P ∘ (dP − delta); the interval mask only on tiles of runs flagged partial
         if (cmask) {
           const int qlim = qidx < ckend ? qidx : ckend - 1;      // keys at or beyond the run end never count
 #pragma unroll
@@ -469,12 +473,12 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
               const int g = 4 * gq + j;
               const bool ok = (ck0 + kl + j <= qlim) && (qidx < sev[j]);
               const float pv = ok ? fast_exp2(__builtin_fmaf(X[g], c, -lse2)) : 0.f;
-              X[g] = pv * __builtin_fmaf(DP[g], p.scale, -delta_s);
+              X[g] = pv * DP[g];
             }
           }
         } else {
 #pragma unroll
-          for (int g = 0; g < 16; ++g) X[g] = fast_exp2(__builtin_fmaf(X[g], c, -lse2)) * __builtin_fmaf(DP[g], p.scale, -delta_s);
+          for (int g = 0; g < 16; ++g) X[g] = fast_exp2(__builtin_fmaf(X[g], c, -lse2)) * DP[g];
         }
         // dQ^T[d][q] += K^T · dS^T
 #pragma unroll
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
       for (int gq = 0; gq < 4; ++gq) {
         v4 w;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = (e)DQ[db][4 * gq + j];
+        for (int j = 0; j < 4; ++j) w[j] = (e)(DQ[db][4 * gq + j] * p.scale);
         *reinterpret_cast<v4*>(dqp + 32 * db + 8 * gq + 4 * h) = w;
       }
   }
