@@ -224,8 +224,16 @@ class TreeTrainingEngine:
         need = per_tok * self.n_layers * T
         if self.device.type != "cuda":
             return False
+        free = self._free_hbm()
+        # `per_tok` over-counts by about 1.3x (Qwen3-0.6B, 25.6k rows: 50 GB estimated, 38 GB of activations measured), so 0.75 of
+        # the free HBM still leaves the head chunk, the gradient buffers and allocator slack their room
+        return need > 0.75 * free
+
+    def _free_hbm(self) -> int:
+        """HBM this process can still use: what the driver reports free plus what torch's caching allocator holds without using
+        (after the first step most of the card is 'reserved'; counting only the driver's number flipped later steps into recomputation)."""
         free, _ = torch.cuda.mem_get_info(self.device)
-        return need > 0.6 * free
+        return int(free + torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device))
 
     def _per_token_layer_bytes(self, model) -> int:
         c = model.config
@@ -237,7 +245,7 @@ class TreeTrainingEngine:
             return int(self.memory_budget_bytes)
         if self.device.type != "cuda":
             return None
-        free, _ = torch.cuda.mem_get_info(self.device)
+        free = self._free_hbm()
         return int(0.8 * free)
 
     def _stack_block_rows(self, model, T: int, block_size: Optional[int]) -> Optional[int]:
@@ -308,7 +316,7 @@ class TreeTrainingEngine:
         as that pays for.  `attn_keep_fraction = 0` recomputes everything."""
         if self.device.type != "cuda" or self.attn_keep_fraction <= 0:
             return 0
-        free, _ = torch.cuda.mem_get_info(self.device)
+        free = self._free_hbm()
         return int(self.attn_keep_fraction * free)
 
     def _path_losses(self, packed, token_trie, lp, ent, loss_fn):
