@@ -435,8 +435,16 @@ def lm_head_rows(h, W, next_tok, fork_ptr, fork_tok, fork_rows, fork_bounds, wan
     `fork_bounds[c] .. fork_bounds[c+1]` = the forks whose row lies in chunk c (host list; used by the vocabulary-split path)."""
     _require_cuda(h, W)
     if keep_bytes is None:
-        free, _ = torch.cuda.mem_get_info(h.device)
+        free, _ = torch.cuda.mem_get_info(h.device)           # + what torch's caching allocator holds unused (most of the card after step 1)
+        free += torch.cuda.memory_reserved(h.device) - torch.cuda.memory_allocated(h.device)
         keep_bytes = free // 4
+    if tp_group is not None:
+        # keeping or chunking the logits sets the NUMBER of collectives below: the ranks of the group must take the same branch
+        # whatever their own free memory is - keep only if every rank can
+        import torch.distributed as dist
+        ok = torch.tensor([1 if h.shape[0] * W.shape[0] * h.element_size() <= keep_bytes else 0], device=h.device, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=tp_group)
+        keep_bytes = (1 << 62) if int(ok.item()) else 0
     lp_next, lp_fork, ent = _HeadRows.apply(h, W, next_tok, fork_ptr, fork_tok, fork_rows, fork_bounds, want_entropy, chunk, keep_bytes,
                                             tp_group, vocab_offset)
     return lp_next, lp_fork, (ent if want_entropy else None)

@@ -363,6 +363,13 @@ class TreeTrainingEngine:
             return 0.0
         n_tree = sum(token_trie.lens) - sum(token_trie.lcp_lens)
         rows = self._stack_block_rows(model, n_tree, block_size)
+        if self.tp_group is not None:
+            # every rank of a vocabulary-parallel group runs the same trie and issues collectives per head call: one pass or the
+            # block-wise walk, and the walk's block size, must not depend on a rank's own free memory - the tightest rank decides
+            import torch.distributed as dist
+            v = torch.tensor([rows if rows is not None else (1 << 30)], device=self.device, dtype=torch.int32)
+            dist.all_reduce(v, op=dist.ReduceOp.MIN, group=self.tp_group)
+            rows = None if int(v.item()) >= (1 << 30) else int(v.item())
         if rows is not None:
             longest = max(token_trie.lens)
             assert longest <= self.max_seq_len, f"Exceeds max_seq_len: cur_len=0, new_tokens={longest}, max={self.max_seq_len}"
