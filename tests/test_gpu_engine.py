@@ -173,6 +173,30 @@ def test_qwen3_0p6b_full_tau2_call_tree_vs_dense_within_recorded_bound():
     assert abs(lt - ld) < 2e-3 * abs(ld)
 
 
+def test_qwen3_0p6b_full_tau2_call_blockwise_walk_equals_one_pass():
+    """The memory-bounded engine at the headline size: the block-wise stack walk (reference schedule, in-place KV stack, fp32 grad-KV)
+    on one full tau2-16k-shaped call gives the loss and every gradient of the one-pass packed engine within the bf16 bar."""
+    cfg = synth.QWEN3_0P6B
+    m = Qwen3TreeLM.from_named(cfg, mo.init_weights(cfg, seed=0), DEV, torch.bfloat16)
+    seqs = synth.as_tensors(synth.tau2(1, cfg["vocab_size"]))
+    att = lambda: [{"w_logprobs": -1.0, "w_entropy": 0.1} for _ in seqs]
+    out = {}
+    for mode in ("packed", "stack"):
+        m.zero_grad(set_to_none=True)
+        t = TokenTrie(seqs, att()); t.backward_permute()
+        e = TreeTrainingEngine(m.config, DEV, torch.bfloat16, 16384); e.mode = mode
+        loss = e.backward(m, t, mo.default_loss, 2048)
+        assert e.last_mode.startswith(mode)
+        out[mode] = (loss, {n: p.grad.float().clone() for n, p in m.named_parameters()})
+    ratios = {n: mo.grad_ratio(out["packed"][1][n], g) for n, g in out["stack"][1].items()}
+    worst = max(ratios.items(), key=lambda kv: kv[1])
+    print(f"full tau2 call: loss packed {out['packed'][0]:.6f} stack {out['stack'][0]:.6f}; worst |dg|/|g| {worst[1]:.4e} ({worst[0]}), "
+          f"median {float(np.median(list(ratios.values()))):.4e}")
+    assert worst[1] <= REF_BF16_BOUND, worst
+    assert float(np.median(list(ratios.values()))) <= 2.55e-2
+    assert abs(out["packed"][0] - out["stack"][0]) < 2e-3 * abs(out["packed"][0])
+
+
 def test_hf_attention_interface_plugin_matches_eager():
     """An unmodified transformers Qwen3 with attn_implementation="dta_mi355x" (prefix K/V through a
     DynamicCache, as the reference engine calls it) against its own eager backend."""
