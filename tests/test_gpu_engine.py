@@ -173,6 +173,25 @@ def test_qwen3_0p6b_full_tau2_call_tree_vs_dense_within_recorded_bound():
     assert abs(lt - ld) < 2e-3 * abs(ld)
 
 
+def test_qwen3_0p6b_full_tau2_call_tree_forward_vs_dense_forward():
+    """`tree_forward` (run.py:28-61) at the headline size: per-sequence logprobs of the shared-prefix pass against the dense
+    per-sequence pass on one full tau2-16k-shaped call, same bar as the bf16-vs-fp32 check of the tiny models (max 0.08, mean 0.015)."""
+    cfg = synth.QWEN3_0P6B
+    m = Qwen3TreeLM.from_named(cfg, mo.init_weights(cfg, seed=0), DEV, torch.bfloat16)
+    seqs = synth.as_tensors(synth.tau2(2, cfg["vocab_size"]))
+    t = TokenTrie(seqs); t.forward_permute()
+    tree = TreeTrainingEngine(m.config, DEV, torch.bfloat16, 16384, forward_only=True).forward(m, t)
+    ref = dense.forward(m, seqs)
+    assert len(tree) == len(ref) == len(seqs)
+    worst, mean, n = 0.0, 0.0, 0
+    for a, b, sq in zip(tree, ref, seqs):
+        assert a.dtype == torch.float32 and a.shape == b.shape == (sq.numel() - 1,)
+        d = (a - b).abs()
+        worst = max(worst, float(d.max())); mean += float(d.sum()); n += d.numel()
+    print(f"full tau2 call forward: {n} logprobs, max |d| {worst:.4e}, mean |d| {mean / n:.4e}")
+    assert worst < 0.08 and mean / n < 0.015
+
+
 def test_qwen3_0p6b_full_tau2_call_blockwise_walk_equals_one_pass():
     """The memory-bounded engine at the headline size: the block-wise stack walk (reference schedule, in-place KV stack, fp32 grad-KV)
     on one full tau2-16k-shaped call gives the loss and every gradient of the one-pass packed engine within the bf16 bar."""
