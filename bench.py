@@ -373,7 +373,7 @@ def main():
                    "calls_per_step": 1 if tp else world, "balancer": "LB_by_DFS_and_TM" if (world > 1 and not tp) else "none",
                    "engine_mode": engine_mode,
                    "grad_allreduce": ("none (vocabulary-parallel run: body replicated, head rows owned per rank)" if tp else
-                                      ("RCCL sum in place on persistent flat buckets, overlapped with backward" if reducer.overlap else "RCCL sum in place after backward")) if world > 1 else "none",
+                                      (("RCCL" if backend == "nccl" else backend + " (rehearsal)") + (" sum in place on persistent flat buckets, overlapped with backward" if reducer.overlap else " sum in place after backward"))) if world > 1 else "none",
                    "value_is": "the WEAK-scaling leg (per-GPU work fixed); the reference's fixed-batch protocol is `strong_scaling`"},
         "tree_tokens_per_s": n_tree / wall, "peak_hbm_gb": peak_hbm / 1e9, "step_ms": acc.get("step_ms"), "step_ms_roofline_leg": acc_r.get("step_ms"),
         "strong_scaling": strong,
