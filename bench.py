@@ -15,7 +15,7 @@ Legs of one invocation (all in the ONE JSON line rank 0 prints):
                        ``timer_overhead_frac``): dominant MFMA kernel vs the 2.5 PFLOP/s peak, HBM-bound kernels vs 8 TB/s.
 * ``cpu_baseline``     (N = 1) the oracle's restatement of the reference schedule on the host cores: config 1 and a tau2-shaped sample.
 
-Other workloads: ``--workload wide`` (BASELINE config 5: 64 x 16 384 over a 1 024-token root, fp16), ``--model qwen3-4b``,
+Other workloads: ``--workload wide`` (BASELINE config 5: 64 x 16 384 over a 1 024-token root, fp16), ``--model qwen3-4b | qwen3-8b | qwen3-14b``,
 ``--vocab-parallel`` (BASELINE config 4: the LM-head vocabulary split over the ranks, vocab_parallel.py:82-396).
 """
 import argparse
@@ -35,7 +35,8 @@ from dynamictreeattn_amd.model import Qwen3TreeLM, make_config
 from dynamictreeattn_amd.token_trie import TokenTrie
 from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine
 
-MODEL_NAME = {"qwen3-0.6b": "Qwen3-0.6B", "qwen3-4b": "Qwen3-4B"}
+MODEL_NAME = {"qwen3-0.6b": "Qwen3-0.6B", "qwen3-4b": "Qwen3-4B", "qwen3-8b": "Qwen3-8B", "qwen3-14b": "Qwen3-14B"}
+MODEL_CFG = {"qwen3-0.6b": synth.QWEN3_0P6B, "qwen3-4b": synth.QWEN3_4B, "qwen3-8b": synth.QWEN3_8B, "qwen3-14b": synth.QWEN3_14B}
 PEAK_TFLOPS = 2500.0               # dense MFMA bf16 / f16 peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0              # HBM3E spec, same table (6 290 GB/s measured copy)
 T_START = time.time()
@@ -143,7 +144,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--block-size", type=int, default=2048)
-    ap.add_argument("--model", default="qwen3-0.6b", choices=["qwen3-0.6b", "qwen3-4b"])
+    ap.add_argument("--model", default="qwen3-0.6b", choices=list(MODEL_NAME))
     ap.add_argument("--workload", default="tau2", choices=["tau2", "wide"])
     ap.add_argument("--vocab-parallel", action="store_true", help="BASELINE config 4: split the LM-head vocabulary over the ranks (every rank runs the same batch)")
     ap.add_argument("--engine-mode", default="auto", choices=["auto", "packed", "stack"])
@@ -175,7 +176,7 @@ def main():
 
     note(rank, f"world {world}, backend {backend}, device {dev}")
     dtype = torch.float16 if wide else torch.bfloat16                     # BASELINE config 5 is fp16
-    cfg = synth.QWEN3_0P6B if args.model == "qwen3-0.6b" else synth.QWEN3_4B
+    cfg = MODEL_CFG[args.model]
     model = build_model(cfg, dev, dtype)
     engine = TreeTrainingEngine(make_config(cfg), dev, dtype, max_seq_len=16384)     # run_all.py:86
     engine.mode = args.engine_mode

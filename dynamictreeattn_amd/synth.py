@@ -19,6 +19,15 @@ QWEN3_4B = dict(vocab_size=151936, hidden_size=2560, intermediate_size=9728, num
                 num_attention_heads=32, num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-6,
                 rope_theta=1000000.0)
 
+# the larger models of exp/exp_dp.py:5-10 (geometry only; weights are random-initialised wherever these are used)
+QWEN3_8B = dict(vocab_size=151936, hidden_size=4096, intermediate_size=12288, num_hidden_layers=36,
+                num_attention_heads=32, num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-6,
+                rope_theta=1000000.0)
+QWEN3_14B = dict(vocab_size=151936, hidden_size=5120, intermediate_size=17408, num_hidden_layers=40,
+                 num_attention_heads=40, num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-6,
+                 rope_theta=1000000.0)
+
+
 def as_tensors(seqs: List[List[int]]) -> List[torch.Tensor]:
     return [torch.tensor(s, dtype=torch.long) for s in seqs]
 
