@@ -182,9 +182,10 @@ class _LayerRecompute(torch.autograd.Function):
 
 
 def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta, checkpoint_layers: bool = False,
-                         attn_keep_bytes: int = 0, attn_of_layer=None) -> torch.Tensor:
+                         attn_keep_bytes: int = 0, attn_of_layer=None, full_layers: int = 0) -> torch.Tensor:
     """Final-norm hidden states [T, hidden] of the packed tokens.  `model` is a Qwen3TreeLM or an HF
-    Qwen2/Qwen3 *ForCausalLM (duck-typed).  `checkpoint_layers`: recompute each layer in the backward;
+    Qwen2/Qwen3 *ForCausalLM (duck-typed).  `checkpoint_layers`: recompute each layer in the backward, except the first
+    `full_layers`, which keep their activations like the plain pass (the caller sizes that number to the HBM that is free);
     `attn_keep_bytes`: HBM budget for attention outputs kept across that recomputation (layers are served first to last).
     `attn_of_layer(l)` -> callable (q, k, v) -> o replaces the packed tree attention (the block-wise engine passes the
     stack form bound to layer l's KV stack; `meta` is unused then)."""
@@ -195,7 +196,7 @@ def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta,
     per_layer = tokens.shape[0] * Hq * (D * res.element_size() + 4)             # out + lse of one layer
     for li, layer in enumerate(body.layers):
         attn = attn_of_layer(li) if attn_of_layer is not None else (lambda q, k, v: ops.tree_attention(q, k, v, meta))
-        if checkpoint_layers and torch.is_grad_enabled():
+        if checkpoint_layers and li >= full_layers and torch.is_grad_enabled():
             keep = attn_of_layer is None and attn_keep_bytes >= per_layer
             if keep:
                 attn_keep_bytes -= per_layer

@@ -201,6 +201,7 @@ class TreeTrainingEngine:
         self.memory_budget_bytes: Optional[int] = None   # activation budget for "auto"; None = 80 % of the free HBM at call time
         self.last_mode: Optional[str] = None             # what the last backward() ran ("packed" / "packed+recompute" / "stack[B]")
         self.attn_keep_fraction = 0.25                   # of free HBM, for attention outputs kept across layer recomputation
+        self.partial_recompute = True                    # under recomputation, leading layers keep full activations while HBM allows
         self.tp_group = None                             # set to a process group to split the LM-head vocabulary across it
 
     # ------------------------------------------------------------------------------------------
@@ -310,6 +311,18 @@ class TreeTrainingEngine:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
+    def _full_layers(self, model, T: int) -> int:
+        """Under per-layer recomputation: how many (leading) layers can still keep their full activations.  Budget = 0.75 of the
+        free HBM minus what the recomputing pass itself holds (two hidden rows per token and layer, one layer's working set twice);
+        the per-layer estimate is the conservative one of `_should_checkpoint`.  0 when `partial_recompute` is off."""
+        if self.device.type != "cuda" or not self.partial_recompute or self.checkpoint_layers is not None:
+            return 0                                   # an explicit `checkpoint_layers = True` means every layer
+        c = model.config
+        per_layer = self._per_token_layer_bytes(model) * T
+        base = T * 2 * 2 * c.hidden_size * self.n_layers + 2 * per_layer
+        budget = int(0.75 * self._free_hbm()) - base
+        return int(max(0, min(self.n_layers, budget // max(per_layer, 1))))
+
     def _attn_keep_bytes(self) -> int:
         """HBM budget for attention outputs kept across the per-layer recomputation (model.py:_LayerRecompute): a quarter
         of what is free when the pass starts, so the recomputation skips the forward attention kernel on as many layers
@@ -378,7 +391,10 @@ class TreeTrainingEngine:
         chunk = min(self.head_chunk, block_size) if block_size else self.head_chunk
         ckpt = self._should_checkpoint(model, packed.plan.T)
         self.last_mode = "packed+recompute" if ckpt else "packed"
-        h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, ckpt, self._attn_keep_bytes() if ckpt else 0)
+        full = self._full_layers(model, packed.plan.T) if ckpt else 0
+        if ckpt and full:
+            self.last_mode = f"packed+recompute[{self.n_layers - full}/{self.n_layers}]"
+        h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, ckpt, self._attn_keep_bytes() if ckpt else 0, None, full)
         lp, ent = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, True, max(chunk, 1),
                                          packed.fork_child, packed.fork_parent, self.tp_group, packed.fork_dev)
         total = self._path_losses(packed, token_trie, lp, ent, loss_fn)
