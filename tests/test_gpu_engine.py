@@ -113,6 +113,35 @@ def test_f16_and_layer_checkpointing_agree():
     assert all(torch.equal(grads[0][n], grads[1][n]) for n in grads[0])
 
 
+def test_partial_recomputation_changes_nothing(monkeypatch):
+    """Under the AUTOMATIC recomputation decision the leading `_full_layers` layers keep their activations (sized to the free HBM):
+    whatever that number is, loss and gradients are those of the plain pass, bit for bit, and the forward attention kernel runs once
+    for a kept layer and twice for a recomputed one."""
+    from dynamictreeattn_amd import ops
+    m, seqs = _setup("d128_minitau", torch.bfloat16)
+    L = m.config.num_hidden_layers
+    att = lambda: [{"w_logprobs": -1.0, "w_entropy": 0.1} for _ in seqs]
+    ref = None
+    for full in (None, 0, 1, L):                       # None: no recomputation at all
+        m.zero_grad(set_to_none=True)
+        t = TokenTrie(seqs, att()); t.backward_permute()
+        e = TreeTrainingEngine(m.config, DEV, torch.bfloat16, max(map(len, seqs)))
+        e.attn_keep_fraction = 0.0
+        monkeypatch.setattr(e, "_should_checkpoint", lambda model, T, f=full: f is not None)
+        monkeypatch.setattr(e, "_full_layers", lambda model, T, f=full: int(f or 0))
+        tm = ops.KernelTimer(); ops.KernelTimer.active = tm
+        try:
+            loss = e.backward(m, t, mo.default_loss, 64)
+        finally:
+            ops.KernelTimer.active = None
+        assert tm.totals_ms()["fwd"][1] == (L if full is None else 2 * L - min(full, L))
+        g = {n: p.grad.clone() for n, p in m.named_parameters()}
+        if ref is None:
+            ref = (loss, g)
+        else:
+            assert loss == ref[0] and all(torch.equal(g[n], ref[1][n]) for n in g), full
+
+
 def test_qwen3_0p6b_config1_tree_vs_dense_within_recorded_bound():
     """BASELINE config 1 at full model size (Qwen3-0.6B dims, 310 tensors, random init seed 0, bf16):
     the exp/compare_grads.py protocol behind grad/Qwen3-0.6B-TB-vs-DB-bf16.txt — per-parameter
