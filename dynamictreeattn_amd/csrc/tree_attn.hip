@@ -59,6 +59,7 @@ struct AttnParams {
   const int32_t *subtree_end, *run_ptr, *runs, *ktile_qend;
   const int32_t *dkv_units, *dkv_splits; float* dkv_ws;     // split-Q work units of the dK/dV sweep (NULL: one unit per key tile)
   int32_t Tq, Tk, q_offset, Hq, Hkv, group;
+  int32_t hgroups, head0;          // forward / dQ launch: workgroups per (query tile, kv head) and the first query head (inside a kv group) they cover
   int64_t q_st, q_sh, kv_st, kv_sh, v_st, v_sh, o_st, o_sh, dq_st, dq_sh, dkv_st, dkv_sh;
   float scale; int32_t accumulate; int32_t ktile;
 };
@@ -266,11 +267,11 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform values live in SGPRs
   const int hb = wave >> 2, rw = wave & 3;
   const int bid = blockIdx.x;
-  const int hgroups = p.group / HPB;
+  const int hgroups = p.hgroups;
   const int kvh = bid % p.Hkv; const int rest = bid / p.Hkv; const int hgb = rest % hgroups;
   const int nqt = (p.Tq + DTA_QTILE - 1) / DTA_QTILE;
   const int qt = nqt - 1 - rest / hgroups;                          // deepest (heaviest) query tiles first
-  const int hq = kvh * p.group + hgb * HPB + hb;
+  const int hq = kvh * p.group + p.head0 + hgb * HPB + hb;
   const int q0 = qt * DTA_QTILE;
   const int qrow = q0 + rw * 32 + r;
   const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
@@ -388,11 +389,11 @@ __global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform values live in SGPRs
   const int hb = wave >> 2, rw = wave & 3;
   const int bid = blockIdx.x;
-  const int hgroups = p.group / HPB;
+  const int hgroups = p.hgroups;
   const int kvh = bid % p.Hkv; const int rest = bid / p.Hkv; const int hgb = rest % hgroups;
   const int nqt = (p.Tq + DTA_QTILE - 1) / DTA_QTILE;
   const int qt = nqt - 1 - rest / hgroups;
-  const int hq = kvh * p.group + hgb * HPB + hb;
+  const int hq = kvh * p.group + p.head0 + hgb * HPB + hb;
   const int q0 = qt * DTA_QTILE;
   const int qrow = q0 + rw * 32 + r;
   const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
@@ -826,12 +827,18 @@ extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v,
   const int nqt = (Tq + DTA_QTILE - 1) / DTA_QTILE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   DTA_REFUSE_IF_PRIOR_ERROR();
-  if (p.group % 2 == 0) {      // two query heads of a kv group share the staged K/V tiles
-    dim3 grid(nqt * Hq / 2), block(512);
+  // two query heads of a kv group share the staged K/V tiles (512 threads); an odd group sends its last head through the
+  // one-head form in a second launch (Qwen3-14B: 40 query / 8 kv heads = 2 pairs + 1 per group)
+  const int npair = p.group / 2;
+  if (npair > 0) {
+    p.hgroups = npair; p.head0 = 0;
+    dim3 grid(nqt * Hkv * npair), block(512);
     if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_BF16, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_F16, 2>), grid, block, 0, st, p);
-  } else {
-    dim3 grid(nqt * Hq), block(256);
+  }
+  if (p.group % 2) {
+    p.hgroups = 1; p.head0 = p.group - 1;
+    dim3 grid(nqt * Hkv), block(256);
     if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_BF16, 1>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_F16, 1>), grid, block, 0, st, p);
   }
@@ -870,14 +877,22 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   if ((which & 7) == 0) return DTA_EINVAL;
   const bool fin = ((which & 2) && !(which & 8)) || (which & 4);     // slab finalize: with the dK/dV launch unless bit3, or alone (bit2)
   const int ndkv = dkv_units ? n_units : nkt;
-  const bool pair = p.group % 2 == 0;
-  const dim3 gq(pair ? nqt * Hq / 2 : nqt * Hq), bq(pair ? 512 : 256);
+  const int npair = p.group / 2;                                     // as in the forward: head pairs, then the odd head alone
+  AttnParams pp = p, ps = p;
+  pp.hgroups = npair; pp.head0 = 0; ps.hgroups = 1; ps.head0 = p.group - 1;
+  const dim3 gqp(nqt * Hkv * (npair > 0 ? npair : 1)), gqs(nqt * Hkv);
   if (dtype == DTA_BF16) {
-    if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 1>), gq, bq, 0, st, p); }
+    if (which & 1) {
+      if (npair > 0) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 2>), gqp, dim3(512), 0, st, pp);
+      if (p.group % 2) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_BF16, 1>), gqs, dim3(256), 0, st, ps);
+    }
     if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv2_kernel<DTA_BF16>), dim3(ndkv * Hkv), dim3(512), 0, st, p);
     if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_BF16>, dim3(n_splits * Hkv, FIN_SPLIT), dim3(256), 0, st, p);
   } else {
-    if (which & 1) { if (pair) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 2>), gq, bq, 0, st, p); else hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 1>), gq, bq, 0, st, p); }
+    if (which & 1) {
+      if (npair > 0) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 2>), gqp, dim3(512), 0, st, pp);
+      if (p.group % 2) hipLaunchKernelGGL((tree_attn_bwd_dq_kernel<DTA_F16, 1>), gqs, dim3(256), 0, st, ps);
+    }
     if (which & 2) hipLaunchKernelGGL((tree_attn_bwd_dkv2_kernel<DTA_F16>), dim3(ndkv * Hkv), dim3(512), 0, st, p);
     if (fin && dkv_units && n_splits > 0) hipLaunchKernelGGL(tree_attn_bwd_dkv_finalize_kernel<DTA_F16>, dim3(n_splits * Hkv, FIN_SPLIT), dim3(256), 0, st, p);
   }
