@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
 // backward part 1: delta + dQ   (query tile owns the workgroup; same sweep as the forward)
 // =================================================================================================
 template <int DT, int HPB>
-__global__ __launch_bounds__(256 * HPB, HPB == 2 ? 2 : 1) void tree_attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256 * HPB, 2) void tree_attn_bwd_dq_kernel(AttnParams p) {
   using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
   __shared__ __attribute__((aligned(16))) char smem[QK_LDS];
 
