@@ -182,10 +182,11 @@ class _LayerRecompute(torch.autograd.Function):
 
 
 def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta, checkpoint_layers: bool = False,
-                         attn_keep_bytes: int = 0, attn_of_layer=None, full_layers: int = 0) -> torch.Tensor:
+                         attn_keep_bytes: int = 0, attn_of_layer=None, full_layers=0, kept_out=None) -> torch.Tensor:
     """Final-norm hidden states [T, hidden] of the packed tokens.  `model` is a Qwen3TreeLM or an HF
     Qwen2/Qwen3 *ForCausalLM (duck-typed).  `checkpoint_layers`: recompute each layer in the backward, except the first
-    `full_layers`, which keep their activations like the plain pass (the caller sizes that number to the HBM that is free);
+    `full_layers`, which keep their activations like the plain pass — an int, or a plan `bytes kept by layer 0 -> number of
+    layers` that is asked once layer 0 has run in full and its footprint has been measured (the number lands in `kept_out`);
     `attn_keep_bytes`: HBM budget for attention outputs kept across that recomputation (layers are served first to last).
     `attn_of_layer(l)` -> callable (q, k, v) -> o replaces the packed tree attention (the block-wise engine passes the
     stack form bound to layer l's KV stack; `meta` is unused then)."""
@@ -194,9 +195,15 @@ def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta,
     res, delta = F.embedding(tokens, body.embed_tokens.weight), None
     cos_sin = ops.rope_cos_sin(depth, D, theta)
     per_layer = tokens.shape[0] * Hq * (D * res.element_size() + 4)             # out + lse of one layer
+    n_full = full_layers if isinstance(full_layers, int) else 1
     for li, layer in enumerate(body.layers):
         attn = attn_of_layer(li) if attn_of_layer is not None else (lambda q, k, v: ops.tree_attention(q, k, v, meta))
-        if checkpoint_layers and li >= full_layers and torch.is_grad_enabled():
+        if li == 0 and callable(full_layers) and checkpoint_layers and torch.is_grad_enabled() and res.is_cuda:
+            m0 = torch.cuda.memory_allocated(res.device)
+            res, delta = _layer_forward(layer, res, delta, cos_sin, attn, Hq, Hkv, D, eps)
+            n_full = int(full_layers(torch.cuda.memory_allocated(res.device) - m0))
+            continue
+        if checkpoint_layers and li >= n_full and torch.is_grad_enabled():
             keep = attn_of_layer is None and attn_keep_bytes >= per_layer
             if keep:
                 attn_keep_bytes -= per_layer
@@ -204,6 +211,8 @@ def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta,
             res, delta = _LayerRecompute.apply(fn, keep, res, delta)
         else:
             res, delta = _layer_forward(layer, res, delta, cos_sin, attn, Hq, Hkv, D, eps)
+    if kept_out is not None:
+        kept_out.append(n_full if checkpoint_layers else len(body.layers))
     return ops.add_rms_norm(res, delta, body.norm.weight, eps)[1]
 
 

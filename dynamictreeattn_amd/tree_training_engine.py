@@ -311,17 +311,22 @@ class TreeTrainingEngine:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
 
-    def _full_layers(self, model, T: int) -> int:
-        """Under per-layer recomputation: how many (leading) layers can still keep their full activations.  Budget = 0.75 of the
-        free HBM minus what the recomputing pass itself holds (two hidden rows per token and layer, one layer's working set twice);
-        the per-layer estimate is the conservative one of `_should_checkpoint`.  0 when `partial_recompute` is off."""
+    def _full_layers(self, model, T: int):
+        """Under per-layer recomputation: how many (leading) layers can still keep their full activations.  Returned as a PLAN
+        `bytes of layer 0 -> number of layers`: the pass runs layer 0 in full, measures what it really kept (the static estimate of
+        `_should_checkpoint` is 1.3-1.5x too high), and the plan divides 0.7 of the HBM free at that moment - minus two layers of
+        working set for the recomputation and the LM head's logits - by it.  0 when `partial_recompute` is off or recomputation
+        was demanded explicitly (`checkpoint_layers = True` means every layer)."""
         if self.device.type != "cuda" or not self.partial_recompute or self.checkpoint_layers is not None:
-            return 0                                   # an explicit `checkpoint_layers = True` means every layer
+            return 0
         c = model.config
-        per_layer = self._per_token_layer_bytes(model) * T
-        base = T * 2 * 2 * c.hidden_size * self.n_layers + 2 * per_layer
-        budget = int(0.75 * self._free_hbm()) - base
-        return int(max(0, min(self.n_layers, budget // max(per_layer, 1))))
+        head = int(2.0 * T * c.vocab_size * 2 + 2 * 4 * c.vocab_size * c.hidden_size)      # logits (+ slack) and the fp32 head gradient
+
+        def plan(layer0_bytes: int) -> int:
+            d0 = max(int(layer0_bytes), 1)
+            budget = int(0.7 * self._free_hbm()) - 2 * d0 - head
+            return int(max(1, min(self.n_layers, 1 + budget // d0)))
+        return plan
 
     def _attn_keep_bytes(self) -> int:
         """HBM budget for attention outputs kept across the per-layer recomputation (model.py:_LayerRecompute): a quarter
@@ -392,9 +397,10 @@ class TreeTrainingEngine:
         ckpt = self._should_checkpoint(model, packed.plan.T)
         self.last_mode = "packed+recompute" if ckpt else "packed"
         full = self._full_layers(model, packed.plan.T) if ckpt else 0
-        if ckpt and full:
-            self.last_mode = f"packed+recompute[{self.n_layers - full}/{self.n_layers}]"
-        h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, ckpt, self._attn_keep_bytes() if ckpt else 0, None, full)
+        kept = []
+        h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, ckpt, self._attn_keep_bytes() if ckpt else 0, None, full, kept)
+        if ckpt and kept:
+            self.last_mode = "packed" if kept[0] >= self.n_layers else f"packed+recompute[{self.n_layers - kept[0]}/{self.n_layers}]"
         lp, ent = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, True, max(chunk, 1),
                                          packed.fork_child, packed.fork_parent, self.tp_group, packed.fork_dev)
         total = self._path_losses(packed, token_trie, lp, ent, loss_fn)
