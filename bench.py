@@ -41,6 +41,8 @@ PEAK_TFLOPS = 2500.0               # dense MFMA bf16 / f16 peak, MI355X_MICROARC
 PEAK_HBM_GBS = 8000.0              # HBM3E spec, same table (6 290 GB/s measured copy)
 T_START = time.time()
 ATTACH = {"w_logprobs": -1.0, "w_entropy": 0.1}      # run_all.py:11-14
+# the bounded tau2-shaped sample the CPU baseline is timed on (and the GPU too, for a like-for-like ratio): 3/8 length scale
+CPU_SAMPLE_CASE = {"kind": "tau2", "seed": 0, "G": 3, "sys_len": 750, "turns": 3, "lo": 75, "hi": 340, "cap": 6144}
 DKV_KERNEL = "tree_attn_bwd_dkv2_kernel"             # the dominant kernel as rocprofv3 names it (8-wave dK/dV)
 HBM_KERNELS = {"dta_logprob_entropy_fwd": "logprob_entropy_fwd_kernel", "dta_logprob_entropy_bwd": "logprob_entropy_bwd_kernel",
                "dta_rmsnorm_fwd": "rmsnorm_fwd_kernel", "dta_rmsnorm_bwd": "rmsnorm_bwd_kernel",
@@ -107,15 +109,24 @@ def cpu_baseline_worker():
     seqs1 = [np.asarray(s, dtype=np.int64) for s in synth.config1(0)]
     run(seqs1)                                                   # warm-up (thread pool, allocator), as run_all.py:88-92
     dt1, st1 = run(seqs1)
-    case = {"kind": "tau2", "seed": 0, "G": 3, "sys_len": 750, "turns": 3, "lo": 75, "hi": 340, "cap": 6144}
-    seqs2 = [np.asarray(s, dtype=np.int64) for s in synth.make_case(case)]
+    seqs2 = [np.asarray(s, dtype=np.int64) for s in synth.make_case(CPU_SAMPLE_CASE)]
     dt2, st2 = run(seqs2)
+    # the FULL tau2 call (48 seqs, ~180k tokens): estimated from the sample by its (query,key) pair count and tree tokens - attention
+    # scales with the pairs, everything else with the tree tokens; it is not run (the leg is bounded to ~30 s of CPU work)
+    full = to.TokenTrieOracle([np.asarray(s, dtype=np.int64) for s in synth.tau2(0)]); full.backward_permute()
+    stf = full.get_stats("backward", 2048)
+    pairs = lambda st: st["sum_depth"] + st["n_tree_tokens"]
+    est_lo = dt2 * stf["n_tree_tokens"] / st2["n_tree_tokens"]
+    est_hi = dt2 * pairs(stf) / pairs(st2)
     print("CPU_BASELINE " + json.dumps({
         "value": st2["n_tokens"] / dt2, "unit": "tokens/s", "cores": threads, "kind": "port",
         "sample": f"tau2-shaped call at 3/8 length scale (G=3, sys 750, 3 turns of 75-340): {st2['n_sequences']} seqs, {st2['n_tokens']} tokens, "
                   f"{st2['n_tree_tokens']} tree tokens, Qwen3-0.6B {name}, reference push/pop schedule, block_size 2048, {dt2:.1f} s on {threads} threads; "
                   "the GPU `value` is measured on the FULL tau2 call (48 seqs, ~180k tokens, ~25.5k tree tokens) — shallower tries favour the CPU",
         "tree_tokens_per_s": st2["n_tree_tokens"] / dt2,
+        "full_call": {"timed": False, "estimate_s": [round(est_lo, 1), round(est_hi, 1)],
+                      "why": f"one full tau2 call would take between {est_lo:.0f} s (scaling the sample by tree tokens, x{stf['n_tree_tokens'] / st2['n_tree_tokens']:.1f}) and "
+                             f"{est_hi:.0f} s (by (query,key) pairs, x{pairs(stf) / pairs(st2):.1f}) on these {threads} threads: outside the bounded CPU leg, so it is not run"},
         "config1": {"value": st1["n_tokens"] / dt1, "unit": "tokens/s", "seconds": dt1,
                     "sample": f"BASELINE config 1: 4 rollouts x 256 tokens sharing a 256-token prompt ({st1['n_tokens']} tokens, {st1['n_tree_tokens']} tree tokens), "
                               f"Qwen3-0.6B {name}, tree backward after one warm-up"}}), flush=True)
@@ -138,6 +149,23 @@ def cpu_baseline(limit_s: int = 300):
 
 
 # --------------------------------------------------------------------------------------------------------------
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as CHILD processes of
+    `python -m torch.distributed.run` (the same command line the driver uses), BEFORE this process has made any GPU call -
+    a process that has touched the GPU is never re-executed.  The children inherit stdout / stderr, so rank 0's single JSON
+    line is this process's output; the exit code is the launcher's (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] WORLD_SIZE is not set: launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this host driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +182,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # decided before anything below touches the GPU
+        sys.exit(self_launch(args.gpus))
     wide = args.workload == "wide"
     steps = args.steps if args.steps is not None else (2 if wide else 6)
     warmup = args.warmup if args.warmup is not None else (1 if wide else 2)
@@ -161,18 +191,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     n_dev = torch.cuda.device_count()
-    local = local % max(n_dev, 1)               # rehearsal on a 1-GPU box: ranks share the card (gloo only, below)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if 0 < n_dev < world:                       # shared card: keep the ranks' caching allocators from oversubscribing the HBM
-        torch.cuda.set_per_process_memory_fraction(0.92 * n_dev / world, dev)      # (3 ranks without it: 144 s per step, paging)
     backend = None
     if world > 1:
-        # RCCL ("nccl") needs one GPU per rank; DTA_BENCH_BACKEND=gloo rehearses the N>1 code path on one GPU
+        # RCCL ("nccl") needs one GPU per rank; DTA_BENCH_BACKEND=gloo rehearses the N>1 code path with ranks sharing a card
         backend = os.environ.get("DTA_BENCH_BACKEND", "nccl")
+        if backend == "nccl" and n_dev < world:
+            raise SystemExit(f"bench.py --gpus {world}: this node shows {n_dev} GPU(s) and RCCL needs one per rank "
+                             "(DTA_BENCH_BACKEND=gloo rehearses the multi-rank path with the ranks sharing the card)")
+    local = local % max(n_dev, 1)               # rehearsal on a 1-GPU box: ranks share the card (gloo only)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if 0 < n_dev < world:                       # shared card: cap every rank's caching allocator at its share of the HBM; the engine's
+        share = (n_dev * 0.92) / world          # footprint decisions (ops.free_hbm) honour the cap, so no rank plans with the whole card
+        torch.cuda.set_per_process_memory_fraction(share, dev)
+    if world > 1:
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     note(rank, f"world {world}, backend {backend}, device {dev}")
     dtype = torch.float16 if wide else torch.bfloat16                     # BASELINE config 5 is fp16
@@ -277,10 +312,13 @@ def main():
                 st_ = TokenTrie(b, device=dev).get_stats("forward")
                 rows.add(engine.packed_rows(st_["n_tree_tokens"]))
         if not wide:
-            engine.warm_gemm_shapes(model, rows)
+            for i_, r_ in enumerate(sorted(rows)):
+                engine.warm_gemm_shapes(model, [r_])
+                note(rank, f"GEMM shapes warmed for {r_} packed rows ({i_ + 1}/{len(rows)}); free HBM for this rank {ops.free_hbm(dev) / 1e9:.1f} GB")
     for s in range(warmup):
         step(weak[s])
-        note(rank, f"warm-up step {s + 1}/{warmup} done")
+        print(f"[bench +{time.time() - T_START:6.1f}s] rank {rank}: warm-up step {s + 1}/{warmup} done, engine mode {engine.last_mode}, "
+              f"free HBM {ops.free_hbm(dev) / 1e9:.1f} GB, peak allocated {torch.cuda.max_memory_allocated(dev) / 1e9:.1f} GB", file=sys.stderr, flush=True)
     zero()
     acc = new_acc()
     wall = timed(weak[warmup:], acc)
@@ -332,6 +370,53 @@ def main():
     except Exception:
         pass
 
+    # ---- TREE_FORWARD leg (run.py:28-61 -> engine.forward): TokenTrie + forward_permute + per-sequence logprobs, same calls
+    fwd_leg = None
+    if not wide and not tp:
+        def fwd_step(mine):
+            trie = TokenTrie(mine, device=dev)
+            if mine:
+                trie.forward_permute()
+            engine.forward(model, trie)
+            return trie.n_tokens
+        zero()
+        fwd_step(weak[0])                                      # warm-up (run_all.py:53-55)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(); t0 = time.time()
+        tok_f = sum(fwd_step(b) for b in weak[warmup:])
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(); wall_f = time.time() - t0
+        tf_ = torch.tensor([wall_f, float(tok_f)], device=dev, dtype=torch.float64)
+        if world > 1:
+            mxf = tf_.clone(); dist.all_reduce(mxf, op=dist.ReduceOp.MAX)
+            smf = tf_.clone(); dist.all_reduce(smf, op=dist.ReduceOp.SUM)
+            wall_f, tok_f = float(mxf[0]), float(smf[1])
+        fwd_leg = {"value": tok_f / wall_f, "unit": "tokens/s", "ms_per_step": wall_f / steps * 1e3,
+                   "definition": "sum n_tokens / wall of TokenTrie build + forward_permute + engine.forward (no-grad logprobs of every sequence, run.py:28-61), same calls as `value`"}
+        note(rank, "tree_forward leg done")
+
+    # ---- the GPU on the CPU baseline's own two workloads (N = 1): like-for-like ratios next to the full-call `value`
+    same_sample = None
+    if world == 1 and not wide and not args.no_cpu_baseline and args.model == "qwen3-0.6b":
+        def gpu_rate(seqs_, reps=3):
+            seqs_ = synth.as_tensors(seqs_)
+            def once():
+                zero()
+                tr = TokenTrie(seqs_, [dict(ATTACH) for _ in seqs_], device=dev); tr.backward_permute()
+                engine.backward(model, tr, loss_fn, 2048)
+                return tr
+            once()                                             # warm-up, as the CPU leg has
+            torch.cuda.synchronize(); t0 = time.time()
+            for _ in range(reps):
+                tr = once()
+            torch.cuda.synchronize(); dt = (time.time() - t0) / reps
+            return {"value": tr.n_tokens / dt, "unit": "tokens/s", "ms": dt * 1e3, "n_tokens": tr.n_tokens}
+        same_sample = {"gpu_config1": gpu_rate(synth.config1(0)), "gpu_same_sample": gpu_rate(synth.make_case(CPU_SAMPLE_CASE))}
+        zero()
+        note(rank, "like-for-like GPU legs done")
+
     # ---- STRONG leg (N > 1, data parallel): the reference's DP protocol on a fixed batch of calls
     strong = None
     if world > 1 and not tp and not args.no_strong and not wide:
@@ -377,7 +462,7 @@ def main():
                                       (("RCCL" if backend == "nccl" else backend + " (rehearsal)") + (" sum in place on persistent flat buckets, overlapped with backward" if reducer.overlap else " sum in place after backward"))) if world > 1 else "none",
                    "value_is": "the WEAK-scaling leg (per-GPU work fixed); the reference's fixed-batch protocol is `strong_scaling`"},
         "tree_tokens_per_s": n_tree / wall, "peak_hbm_gb": peak_hbm / 1e9, "step_ms": acc.get("step_ms"), "step_ms_roofline_leg": acc_r.get("step_ms"),
-        "strong_scaling": strong,
+        "strong_scaling": strong, "tree_forward": fwd_leg,
         "roofline": {"bound": "mfma", "kernel": DKV_KERNEL, "achieved": dkv_tf, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": dkv_tf / PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dkv_ms,
                      "flops_per_pair_per_layer": 8 * Hq * D, "pairs_per_step": pairs_r / max(steps, 1),
@@ -395,7 +480,14 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            cb = cpu_baseline()
+            if same_sample is not None and cb.get("value"):
+                # like for like: the GPU timed on exactly the two workloads the CPU ran (after one warm-up each, as the CPU leg)
+                cb["gpu_same_sample"] = dict(same_sample["gpu_same_sample"], ratio_gpu_over_cpu=same_sample["gpu_same_sample"]["value"] / cb["value"])
+                cb["gpu_config1"] = dict(same_sample["gpu_config1"], ratio_gpu_over_cpu=same_sample["gpu_config1"]["value"] / cb["config1"]["value"])
+                cb["note"] = ("`value` of this object and `gpu_same_sample` are the SAME bounded sample; `config1` and `gpu_config1` the same BASELINE config 1; "
+                              "the headline `value` of the line is the full tau2 call, which the CPU leg does not run (see full_call)")
+            out["cpu_baseline"] = cb
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -25,7 +25,7 @@
 // tile-end barrier, so a tile's DMA has the whole compute phase of the previous tile to land.
 //
 // Lane maps used here were verified on hardware by tests/micro/mfma_layout_probe.hip.
-// The round-1 ablation switches (-DDTA_ABL) and the retired 4-wave dK/dV kernel live in csrc/diag/ (not built).
+// The round-1 ablation switches (-DDTA_ABL) and the retired 4-wave dK/dV kernel live in scripts/diag/ (not built).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -111,3 +111,39 @@ def eval(token_seqs, bins, time_model, args):
         total += t
         worst = max(worst, t)
     return total, worst
+
+
+def partition_folder(data_folder: str, out_folder: Optional[str], method: str, K: int, mode: str = "forward", block_size: Optional[int] = None,
+                     time_model=None, stats_file: Optional[str] = None, evaluate: bool = False):
+    """The body of the reference's CLI (data_parallel.py:153-204): every `<name>.pt` batch of `data_folder` is split into K bins by
+    `method` and written as `{name}_bin{k}.pt` (lists of LongTensors, input order inside a bin = the balancer's) into `out_folder`.
+    `stats_file`: a stats JSONL (run_all.py:162-165) that trains the time model first; `evaluate`: also return the summed
+    predicted (total, max-bin) times.  Returns {"bins": {name: bins}, "total_time": .., "max_time": ..}."""
+    import types
+
+    from . import io
+    from .tree_time_model import TreeTimeModel
+    if mode == "forward":
+        block_size = None                                        # data_parallel.py:155-156
+    tm_eval = TreeTimeModel()
+    if stats_file is not None:
+        tm_eval.add_data(io.read_stats(stats_file))
+    tm = time_model if time_model is not None else tm_eval
+    args = types.SimpleNamespace(K=K, mode=mode, block_size=block_size)
+    out = {"bins": {}, "total_time": 0.0, "max_time": 0.0}
+    for name, inputs in io.load_folder(data_folder):
+        if method == "LB_by_n_tokens":
+            bins = LB_by_n_tokens(inputs, K)
+        elif method == "LB_by_TM":
+            bins = LB_by_TM(inputs, tm, args)
+        elif method == "LB_by_DFS_and_TM":
+            bins = LB_by_DFS_and_TM(inputs, tm, args)
+        else:
+            raise ValueError(f"Unsupported method: {method}")
+        out["bins"][name] = bins
+        if stats_file is not None and evaluate:
+            total, worst = eval(inputs, bins, tm_eval, args)
+            out["total_time"] += total; out["max_time"] += worst
+        if out_folder is not None:
+            io.save_bins(out_folder, name, inputs, bins)
+    return out

@@ -128,6 +128,8 @@ class GradReducer:
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 if p.grad is not None:
                     v.copy_(p.grad)
+                else:
+                    v.zero_()              # "no gradient" is zero: the buffer still holds the previous step's reduced sums
                 p.grad = v
         self._left = [len(b) for b in self.buckets]
         self._next = 0                    # next bucket index to launch

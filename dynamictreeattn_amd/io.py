@@ -62,7 +62,7 @@ def save_gradients(model, path: str) -> None:
 
 
 def compare_grads(base: Dict[str, Optional[torch.Tensor]], exp: Dict[str, Optional[torch.Tensor]], eps: float = 1e-6):
-    """[(name, |Δg|/|g|, |g_base|, |g_exp|)] sorted by the ratio, descending."""
+    """[(name, |Δg|/|g|, |g_base|, |g_exp|)] sorted by the ratio, descending (exp/compare_grads.py:42-62)."""
     rows = []
     for n in sorted(set(base) & set(exp)):
         if base[n] is None or exp[n] is None:
@@ -73,8 +73,59 @@ def compare_grads(base: Dict[str, Optional[torch.Tensor]], exp: Dict[str, Option
     return rows
 
 
-def format_compare_table(rows) -> str:
+def format_compare_table(rows, n_common: Optional[int] = None, missing_in_exp: Iterable[str] = (), missing_in_base: Iterable[str] = ()) -> str:
+    """The text exp/compare_grads.py:26-76 writes: optional missing-key warnings, "Comparing N common parameters" (N counts the
+    common KEYS, entries that are None on either side included), header, rule, one row per compared parameter."""
+    lines = []
+    missing_in_exp, missing_in_base = sorted(missing_in_exp), sorted(missing_in_base)
+    if missing_in_exp:
+        lines.append(f"[Warning] Missing in exp-grad ({len(missing_in_exp)}):")
+        lines += [f"  {k}" for k in missing_in_exp]
+    if missing_in_base:
+        lines.append(f"[Warning] Missing in baseline-grad ({len(missing_in_base)}):")
+        lines += [f"  {k}" for k in missing_in_base]
     head = f"{'Parameter':60s} {'|Δg|/|g|':>12s} {'|g_baseline|':>12s} {'|g_exp|':>12s}"
-    lines = [f"\nComparing {len(rows)} common parameters\n", head, "-" * 104]
+    lines += [f"\nComparing {len(rows) if n_common is None else n_common} common parameters\n", head, "-" * 104]
     lines += [f"{n:60s} {r:12.4e} {a:12.4e} {b:12.4e}" for n, r, a, b in rows]
     return "\n".join(lines)
+
+
+def compare_grads_report(base: Dict[str, Optional[torch.Tensor]], exp: Dict[str, Optional[torch.Tensor]]) -> str:
+    """exp/compare_grads.py as one call on two loaded dumps."""
+    return format_compare_table(compare_grads(base, exp), len(set(base) & set(exp)), set(base) - set(exp), set(exp) - set(base))
+
+
+def parse_compare_table(text: str):
+    """Rows [(name, ratio, |g_base|, |g_exp|)] of a table in exp/compare_grads.py's format, e.g. the reference's recorded
+    grad/Qwen3-0.6B-TB-vs-DB-bf16.txt."""
+    rows, body = [], False
+    for ln in text.split("\n"):
+        if ln.startswith("-" * 20):
+            body = True
+        elif body and ln.strip():
+            name, ratio, a, b = ln.split()
+            rows.append((name, float(ratio), float(a), float(b)))
+    return rows
+
+
+STATS_KEYS = {                                   # run.py:57-60 / 110-112 + run_all.py:60 / 98 (the order json.dumps writes them in)
+    "tree_forward": ("n_leaf_sequences", "n_tree_tokens", "sum_prefix_len", "sum_depth", "n_sequences", "n_tokens", "time", "name"),
+    "tree_backward": ("n_leaf_sequences", "n_tree_tokens", "sum_prefix_len", "sum_depth", "n_f1_tokens", "n_sequences", "n_tokens",
+                      "loss", "time", "name"),
+}
+
+
+def stats_row(trie, run: str, seconds: float, name: str, loss: Optional[float] = None, block_size: Optional[int] = None) -> dict:
+    """One stats row of `run` ∈ {tree_forward, tree_backward} for a TokenTrie in the order it was run in — the dict run.py
+    returns and run_all.py:162-165 writes as a JSONL line; `TreeTimeModel.add_data` and exp/calc_time.py read these keys."""
+    if run == "tree_forward":
+        st = trie.get_stats(mode="forward")
+    elif run == "tree_backward":
+        st = trie.get_stats(mode="backward", block_size=block_size)
+        st["loss"] = float(loss if loss is not None else 0.0)
+    else:
+        raise ValueError(f"Unsupported run: {run}")
+    st["time"] = float(seconds)
+    st["name"] = name
+    assert tuple(st) == STATS_KEYS[run], tuple(st)
+    return st

@@ -77,6 +77,22 @@ def _require_cuda(*ts):
     _on(*ts)
 
 
+def free_hbm(device) -> int:
+    """HBM THIS PROCESS can still use on `device`: the smaller of
+    * what the driver reports free on the card (device-wide: other processes' allocations are already taken out) plus what
+      torch's caching allocator holds without using (after the first step most of the card is 'reserved'), and
+    * what is left under this process's allocator cap (`torch.cuda.set_per_process_memory_fraction`: ranks that share a card,
+      or a co-tenant's reservation) - `mem_get_info` alone knows nothing about that cap, so every rank of a shared card used to
+      size its logits / activation budgets from the WHOLE free card."""
+    free, total = torch.cuda.mem_get_info(device)
+    alloc, reserved = torch.cuda.memory_allocated(device), torch.cuda.memory_reserved(device)
+    usable = free + reserved - alloc
+    frac = torch.cuda.get_per_process_memory_fraction(device)
+    if frac < 1.0:
+        usable = min(usable, int(frac * total) - alloc)
+    return max(int(usable), 0)
+
+
 def _launch(name: str, tensors, *args, nbytes: int = 0):
     """One C-ABI call on the device / current stream of `tensors` (see _on); raises on a non-zero status.
     `nbytes`: algorithmic HBM bytes of the launch (one read of every input, one write of every output) for the roofline leg."""
@@ -435,9 +451,7 @@ def lm_head_rows(h, W, next_tok, fork_ptr, fork_tok, fork_rows, fork_bounds, wan
     `fork_bounds[c] .. fork_bounds[c+1]` = the forks whose row lies in chunk c (host list; used by the vocabulary-split path)."""
     _require_cuda(h, W)
     if keep_bytes is None:
-        free, _ = torch.cuda.mem_get_info(h.device)           # + what torch's caching allocator holds unused (most of the card after step 1)
-        free += torch.cuda.memory_reserved(h.device) - torch.cuda.memory_allocated(h.device)
-        keep_bytes = free // 4
+        keep_bytes = free_hbm(h.device) // 4
     if tp_group is not None:
         # keeping or chunking the logits sets the NUMBER of collectives below: the ranks of the group must take the same branch
         # whatever their own free memory is - keep only if every rank can
@@ -710,17 +724,40 @@ def swiglu_fused(gu: torch.Tensor) -> torch.Tensor:
 class _StackRows(torch.autograd.Function):
     """Concatenate weight matrices along dim 0 into one GEMM operand.  Backward hands each input its row
     slice of the fused gradient as a VIEW (no copy); forward is len(ws) plain copies (torch.cat's batched
-    copy kernel took 170 us for two 6 MB inputs on gfx950)."""
+    copy kernel took 170 us for two 6 MB inputs on gfx950) - and none at all when the same weights, unchanged
+    (same storage, same in-place version counter), were stacked before: every layer call of a step, the recomputation
+    pass and every block of the block-wise walk then share ONE fused copy until the optimizer updates the weights."""
+
+    CACHE_BYTES = 8 << 30            # fused copies kept at most (Qwen3-0.6B: 0.59 GB, Qwen3-4B: 4.7 GB); beyond it, copy per call
+    _cache: dict = {}
+    _cached_bytes = 0
 
     @staticmethod
-    def forward(ctx, *ws):
+    def _fused(ws):
+        key = tuple(id(w) for w in ws)
+        sig = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws)
+        hit = _StackRows._cache.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
         rows = [w.shape[0] for w in ws]
-        out = torch.empty((sum(rows),) + tuple(ws[0].shape[1:]), dtype=ws[0].dtype, device=ws[0].device)
+        reuse = hit is not None and hit[1].dtype == ws[0].dtype and hit[1].device == ws[0].device and hit[1].shape[0] == sum(rows)
+        out = hit[1] if reuse else torch.empty((sum(rows),) + tuple(ws[0].shape[1:]), dtype=ws[0].dtype, device=ws[0].device)
         o = 0
         for w, r in zip(ws, rows):
             out[o:o + r].copy_(w); o += r
-        ctx.rows = rows
+        nbytes = out.numel() * out.element_size()
+        if reuse:
+            _StackRows._cache[key] = (sig, out)
+        elif _StackRows._cached_bytes + nbytes <= _StackRows.CACHE_BYTES:
+            if hit is not None:
+                _StackRows._cached_bytes -= hit[1].numel() * hit[1].element_size()
+            _StackRows._cache[key] = (sig, out); _StackRows._cached_bytes += nbytes
         return out
+
+    @staticmethod
+    def forward(ctx, *ws):
+        ctx.rows = [w.shape[0] for w in ws]
+        return _StackRows._fused(ws).detach()           # a fresh alias: autograd attaches this call's node to it, not to the cached buffer
 
     @staticmethod
     def backward(ctx, g):
@@ -732,6 +769,10 @@ class _StackRows(torch.autograd.Function):
 
 def stack_rows(*ws: torch.Tensor) -> torch.Tensor:
     return _StackRows.apply(*ws)
+
+
+def clear_stack_rows_cache() -> None:
+    _StackRows._cache.clear(); _StackRows._cached_bytes = 0
 
 
 class _Linear(torch.autograd.Function):

@@ -31,6 +31,7 @@ import torch
 
 from . import ops
 from .model import _cfg_of, head_weight, packed_hidden_states
+from .tree_training_engine import sum_loss_terms
 from .trie import pop_block_starts
 
 
@@ -161,8 +162,9 @@ class StackWalk:
             pre_ent = self.ent[:s].detach().clone().requires_grad_(True)
             lp_vec, ent_vec = torch.cat([pre_lp, lp_in]), torch.cat([pre_ent, ent])
             terms = [loss_fn(lp_vec[:n - 1], ent_vec[:n], att) for att, n in here]
-            loss = terms[0] if len(terms) == 1 else torch.stack([t.reshape(()) for t in terms]).sum()
-            roots.append(loss); grads.append(None)
+            loss = sum_loss_terms(terms, self.dev)
+            if loss.requires_grad:                 # a callback may return constants for the sequences of a block
+                roots.append(loss); grads.append(None)
         torch.autograd.backward(roots, grads)
         if pre_lp is not None and s > 0:
             if pre_lp.grad is not None:

@@ -41,7 +41,10 @@ class _DeviceTokens:
         np.cumsum(lens, out=starts[1:])
         from ._staging import upload
         flat = torch.cat([t.reshape(-1).to(torch.long) for t in inputs]) if inputs else torch.zeros(0, dtype=torch.long)
-        self.tokens = upload([flat.numpy()], device, np.int64)[0]          # one asynchronous copy out of page-locked staging
+        if flat.is_cuda:                      # token ids that already live on a GPU (the reference takes tensors on any device)
+            self.tokens = flat.to(device)
+        else:
+            self.tokens = upload([flat.numpy()], device, np.int64)[0]      # one asynchronous copy out of page-locked staging
         self.starts = starts[:-1].copy()      # per ORIGINAL sequence id
         self.lens = np.asarray(lens, np.int32)
         self.device = device

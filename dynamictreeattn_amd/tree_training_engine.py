@@ -108,6 +108,15 @@ def packed_logprob_entropy(h: torch.Tensor, W: torch.Tensor, tokens: torch.Tenso
     return lp, ent
 
 
+def sum_loss_terms(terms, device):
+    """Sum of the per-sequence losses (tte:396-398 `loss += loss_fn(...)`).  `loss_fn` returns a 0-d tensor; a plain Python
+    number (a constant term for some sequence, which the reference's `0.0 + ...` tolerates) is accepted too.  None if empty."""
+    if not terms:
+        return None
+    ts = [t if isinstance(t, torch.Tensor) else torch.as_tensor(float(t), dtype=torch.float32, device=device) for t in terms]
+    return ts[0].reshape(()) if len(ts) == 1 else torch.stack([t.reshape(()).float() for t in ts]).sum()
+
+
 # --------------------------------------------------------------------------------------------------
 class _PackedTrie:
     """Device-resident packed form of a TokenTrie (in its current leaf order)."""
@@ -203,6 +212,7 @@ class TreeTrainingEngine:
         self.attn_keep_fraction = 0.25                   # of free HBM, for attention outputs kept across layer recomputation
         self.partial_recompute = True                    # under recomputation, leading layers keep full activations while HBM allows
         self.tp_group = None                             # set to a process group to split the LM-head vocabulary across it
+        self._attn_keep_planned = 0
 
     # ------------------------------------------------------------------------------------------
     def _pack(self, token_trie) -> _PackedTrie:
@@ -231,10 +241,9 @@ class TreeTrainingEngine:
         return need > 0.75 * free
 
     def _free_hbm(self) -> int:
-        """HBM this process can still use: what the driver reports free plus what torch's caching allocator holds without using
-        (after the first step most of the card is 'reserved'; counting only the driver's number flipped later steps into recomputation)."""
-        free, _ = torch.cuda.mem_get_info(self.device)
-        return int(free + torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device))
+        """HBM this process can still use (ops.free_hbm: driver-free + the caching allocator's unused reserve, under the
+        per-process allocator cap when one is set)."""
+        return ops.free_hbm(self.device)
 
     def _per_token_layer_bytes(self, model) -> int:
         c = model.config
@@ -321,10 +330,12 @@ class TreeTrainingEngine:
             return 0
         c = model.config
         head = int(2.0 * T * c.vocab_size * 2 + 2 * 4 * c.vocab_size * c.hidden_size)      # logits (+ slack) and the fp32 head gradient
+        stash = self.n_layers * 2 * T * c.hidden_size * 2                                    # (res, delta) kept per recomputed layer
+        attn_keep = self._attn_keep_planned                                                  # already promised to kept attention outputs
 
         def plan(layer0_bytes: int) -> int:
             d0 = max(int(layer0_bytes), 1)
-            budget = int(0.7 * self._free_hbm()) - 2 * d0 - head
+            budget = int(0.7 * self._free_hbm()) - 2 * d0 - head - stash - attn_keep
             return int(max(1, min(self.n_layers, 1 + budget // d0)))
         return plan
 
@@ -332,10 +343,12 @@ class TreeTrainingEngine:
         """HBM budget for attention outputs kept across the per-layer recomputation (model.py:_LayerRecompute): a quarter
         of what is free when the pass starts, so the recomputation skips the forward attention kernel on as many layers
         as that pays for.  `attn_keep_fraction = 0` recomputes everything."""
+        self._attn_keep_planned = 0
         if self.device.type != "cuda" or self.attn_keep_fraction <= 0:
             return 0
         free = self._free_hbm()
-        return int(self.attn_keep_fraction * free)
+        self._attn_keep_planned = int(self.attn_keep_fraction * free)
+        return self._attn_keep_planned
 
     def _path_losses(self, packed, token_trie, lp, ent, loss_fn):
         """Σ over original sequences of loss_fn(logprobs[:len-1], entropy[:len], attachment) (tte:379-398).  The root paths of
@@ -347,9 +360,7 @@ class TreeTrainingEngine:
             for attachment, length in attach_list:
                 terms.append(loss_fn(lp_all[o + 1:o + length], ent_all[o:o + length], attachment))
             o += packed.path_sizes[i]
-        if not terms:
-            return None
-        return terms[0] if len(terms) == 1 else torch.stack([t.reshape(()) for t in terms]).sum()
+        return sum_loss_terms(terms, lp.device)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -396,9 +407,10 @@ class TreeTrainingEngine:
         chunk = min(self.head_chunk, block_size) if block_size else self.head_chunk
         ckpt = self._should_checkpoint(model, packed.plan.T)
         self.last_mode = "packed+recompute" if ckpt else "packed"
+        attn_keep = self._attn_keep_bytes() if ckpt else 0          # before the layer plan: the plan leaves this much alone
         full = self._full_layers(model, packed.plan.T) if ckpt else 0
         kept = []
-        h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, ckpt, self._attn_keep_bytes() if ckpt else 0, None, full, kept)
+        h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, ckpt, attn_keep, None, full, kept)
         if ckpt and kept:
             self.last_mode = "packed" if kept[0] >= self.n_layers else f"packed+recompute[{self.n_layers - kept[0]}/{self.n_layers}]"
         lp, ent = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, True, max(chunk, 1),
@@ -406,6 +418,7 @@ class TreeTrainingEngine:
         total = self._path_losses(packed, token_trie, lp, ent, loss_fn)
         if total is None:
             return 0.0
-        total.backward()
+        if total.requires_grad:                     # (a callback that returns constants only leaves nothing to back-propagate)
+            total.backward()
         self.cur_len = 0
         return float(total.item())

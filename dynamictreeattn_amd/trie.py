@@ -127,7 +127,9 @@ class CompressedTrie:
                 nd.chain_tail_depth = nd.depth
             elif phase == 0:
                 work.append((nid, 1))
-                work.extend((c, 0) for c in nd.child_ids)
+                # children in creation order (the stack pops from the end): a random ranking then draws from the RNG in the
+                # reference's post-order, so `get_order_random(seed=None)` under a seeded global RNG gives the reference's order
+                work.extend((c, 0) for c in reversed(nd.child_ids))
             else:
                 nd.chain_tail_depth = nodes[self._rank(nid, how, seed)[0]].chain_tail_depth
 

@@ -3,7 +3,7 @@
 // dK/dV with ONE wave per SIMD, 64 keys per wave, S/dP through inline-asm VGPR-form MFMAs and a hand-placed 64-gap schedule.
 // Bit-identical to the product kernel in tests/test_gpu_attention.py and within +-1 % of its time.
 // A/B build:  hipcc --offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -DDTA_DKV3 -o build/libdta_dkv3.so \
-//               dynamictreeattn_amd/csrc/diag/tree_attn_dkv3_experiment.hip dynamictreeattn_amd/csrc/{trie,elementwise,logprob}_kernels.hip
+//               scripts/diag/tree_attn_dkv3_experiment.hip dynamictreeattn_amd/csrc/{trie,elementwise,logprob}_kernels.hip
 //             DTA_LIB=$PWD/build/libdta_dkv3.so python scripts/attn_bench.py 10
 // Timing-only switches (results wrong): -DKV3_T_VALU=0 -DKV3_T_LD=0 -DKV3_T_TR=0 -DKV3_TIMING_DMA=0 -DKV3_TIMING_NOBARRIER
 // =====================================================================================================================
@@ -34,7 +34,7 @@
 // tile-end barrier, so a tile's DMA has the whole compute phase of the previous tile to land.
 //
 // Lane maps used here were verified on hardware by tests/micro/mfma_layout_probe.hip.
-// The round-1 ablation switches (-DDTA_ABL) and the retired 4-wave dK/dV kernel live in csrc/diag/ (not built).
+// The round-1 ablation switches (-DDTA_ABL) and the retired 4-wave dK/dV kernel live in scripts/diag/ (not built).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sustained bf16 MFMA rate by shape on random and on zero operands (diagnostic; see csrc/diag/mfma_shape_probe.hip)."""
+"""Sustained bf16 MFMA rate by shape on random and on zero operands (diagnostic; see scripts/diag/mfma_shape_probe.hip)."""
 import ctypes as C, os, sys, json
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -4,7 +4,7 @@ set -o pipefail
 OUT=gpurun_out/pmc_dkv3
 mkdir -p $OUT
 export TMPDIR=/tmp
-export DTA_LIB=$PWD/build/${1:-libdta_dkv3.so}     # built from csrc/diag/tree_attn_dkv3_experiment.hip (see its header)
+export DTA_LIB=$PWD/build/${1:-libdta_dkv3.so}     # built from scripts/diag/tree_attn_dkv3_experiment.hip (see its header)
 for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
   tag=$(echo $grp | tr ' ' '+' | cut -c1-40)
   echo "[pmc] $grp"; date

@@ -15,6 +15,67 @@ TINY_CFGS: Dict[str, dict] = {
 
 
 
+# Qwen2-style geometry: q/k/v biases, no per-head q/k RMSNorm, head_dim = hidden / heads = 128 (INTEGRATION.md claims Qwen2 support)
+QWEN2_TINY = dict(vocab_size=512, hidden_size=256, intermediate_size=320, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                  head_dim=128, rms_norm_eps=1e-6, rope_theta=1000000.0)
+
+
+def qwen2_weights(cfg: dict = None, seed: int = 5, std: float = 0.02) -> Dict[str, torch.Tensor]:
+    """Seeded fp32 weights with the HF Qwen2 parameter names (tied head)."""
+    cfg = cfg or QWEN2_TINY
+    g = torch.Generator().manual_seed(seed)
+    H, I, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
+    Hq, Hkv, D = cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"]
+    w = {"model.embed_tokens.weight": torch.randn(V, H, generator=g) * std}
+    for l in range(cfg["num_hidden_layers"]):
+        p = f"model.layers.{l}."
+        for nm, o in (("q", Hq * D), ("k", Hkv * D), ("v", Hkv * D)):
+            w[p + f"self_attn.{nm}_proj.weight"] = torch.randn(o, H, generator=g) * std
+            w[p + f"self_attn.{nm}_proj.bias"] = torch.randn(o, generator=g) * 0.1
+        w[p + "self_attn.o_proj.weight"] = torch.randn(H, Hq * D, generator=g) * std
+        w[p + "mlp.gate_proj.weight"] = torch.randn(I, H, generator=g) * std
+        w[p + "mlp.up_proj.weight"] = torch.randn(I, H, generator=g) * std
+        w[p + "mlp.down_proj.weight"] = torch.randn(H, I, generator=g) * std
+        w[p + "input_layernorm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
+        w[p + "post_attention_layernorm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
+    w["model.norm.weight"] = 1.0 + 0.1 * torch.randn(H, generator=g)
+    return w
+
+
+def hf_qwen2(weights=None, cfg: dict = None):
+    """transformers.Qwen2ForCausalLM of QWEN2_TINY with the seeded weights (fp32, eager attention)."""
+    import transformers
+    cfg = cfg or QWEN2_TINY
+    c = transformers.Qwen2Config(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+                                 num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+                                 num_key_value_heads=cfg["num_key_value_heads"], tie_word_embeddings=True, max_position_embeddings=40960,
+                                 rms_norm_eps=cfg["rms_norm_eps"], rope_parameters={"rope_type": "default", "rope_theta": cfg["rope_theta"]})
+    c._attn_implementation = "eager"
+    m = transformers.Qwen2ForCausalLM(c)
+    w = weights or qwen2_weights(cfg)
+    missing, unexpected = m.load_state_dict({**w, "lm_head.weight": w["model.embed_tokens.weight"]}, strict=False)
+    assert not unexpected and all("rotary" in k for k in missing), (missing, unexpected)
+    return m.float().train()
+
+
+def hf_qwen3(cfg: dict, weights: Dict[str, torch.Tensor]):
+    """transformers.Qwen3ForCausalLM of a TINY_CFGS geometry with the given named weights (fp32, eager attention)."""
+    import transformers
+    c = transformers.Qwen3Config(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"], intermediate_size=cfg["intermediate_size"],
+                                 num_hidden_layers=cfg["num_hidden_layers"], num_attention_heads=cfg["num_attention_heads"],
+                                 num_key_value_heads=cfg["num_key_value_heads"], head_dim=cfg["head_dim"], tie_word_embeddings=True,
+                                 max_position_embeddings=40960, rms_norm_eps=cfg["rms_norm_eps"],
+                                 rope_parameters={"rope_type": "default", "rope_theta": cfg["rope_theta"]})
+    c._attn_implementation = "eager"
+    m = transformers.Qwen3ForCausalLM(c)
+    missing, unexpected = m.load_state_dict({**weights, "lm_head.weight": weights["model.embed_tokens.weight"]}, strict=False)
+    assert not unexpected and all("rotary" in k for k in missing), (missing, unexpected)
+    return m.float().train()
+
+
+QWEN2_DATA = {"kind": "tau2", "seed": 6, "V": 512, "G": 3, "sys_len": 20, "turns": 3, "lo": 5, "hi": 15, "cap": 64}
+
+
 def trie_cases() -> List[dict]:
     cases = [
         {"kind": "literal", "seqs": [[1, 2, 3]]},                                   # single sequence

@@ -129,6 +129,66 @@ def _cpu_swiglu_fused(gu):
     return torch.nn.functional.silu(gu[..., :C]) * gu[..., C:]
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# vocab_parallel on host tensors (the product raises there): a torch restatement of vocab_parallel.py:13-27 (local) and
+# :82-370 (vocabulary-sharded, with the product's packed collectives: ONE MAX + ONE SUM), used by the gloo tests.
+# ------------------------------------------------------------------------------------------------------------------
+class _CpuShardedLogProbEntropy(torch.autograd.Function):
+    """Shard = contiguous slice rank·V/tp (vocab_parallel.py:128-130); labels are shard-local, -1 = not mine / no label."""
+
+    @staticmethod
+    def forward(ctx, x2, lab_local, group, want_entropy):
+        import torch.distributed as dist
+        mx = x2.max(dim=-1).values
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        e = torch.exp(x2 - mx[:, None])
+        mine = lab_local >= 0
+        idx = lab_local.clamp(min=0)
+        picked = torch.where(mine, x2.gather(-1, idx[:, None]).squeeze(-1) - mx, torch.zeros_like(mx))
+        packed = torch.stack([e.sum(-1), picked, (e * x2).sum(-1)], dim=-1)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        z, picked, ex = packed.unbind(-1)
+        logz = mx + torch.log(z)
+        mean_x = ex / z
+        ctx.save_for_backward(x2, logz, mean_x, mine, idx)
+        ctx.want_entropy = want_entropy
+        return picked - torch.log(z), (logz - mean_x)
+
+    @staticmethod
+    def backward(ctx, g_lp, g_ent):
+        x2, logz, mean_x, mine, idx = ctx.saved_tensors
+        p = torch.exp(x2 - logz[:, None])
+        g = -p * g_lp.reshape(-1, 1)
+        if ctx.want_entropy and g_ent is not None:
+            g = g + g_ent.reshape(-1, 1) * p * (mean_x[:, None] - x2)
+        g.scatter_add_(-1, idx[:, None], (g_lp.reshape(-1) * mine)[:, None].to(g.dtype))
+        return g, None, None, None
+
+
+def _cpu_logprob_entropy(logits2d, labels1d, temperature, want_entropy, tp_group):
+    """Stand-in of vocab_parallel._device_logprob_entropy: labels int64 [R], -1 = no label (log-prob 0)."""
+    x = logits2d.float() / temperature if temperature != 1.0 else logits2d.float()
+    if tp_group is None:
+        lp_all = torch.log_softmax(x, dim=-1)
+        lp = lp_all.gather(-1, labels1d.clamp(min=0)[:, None]).squeeze(-1) * (labels1d >= 0)
+        return lp, (-(lp_all.exp() * lp_all).sum(-1) if want_entropy else None)
+    import torch.distributed as dist
+    V = x.shape[1]
+    lo = dist.get_rank(tp_group) * V
+    lab = torch.where((labels1d >= lo) & (labels1d < lo + V), labels1d - lo, torch.full_like(labels1d, -1))
+    lp, ent = _CpuShardedLogProbEntropy.apply(x, lab, tp_group, want_entropy)
+    return lp, (ent if want_entropy else None)
+
+
+def install_cpu_logprob(monkeypatch=None):
+    """Patch the host restatement over the product's device entry (spawned gloo workers call this without a monkeypatch)."""
+    from dynamictreeattn_amd import vocab_parallel
+    if monkeypatch is None:
+        vocab_parallel._device_logprob_entropy = _cpu_logprob_entropy
+    else:
+        monkeypatch.setattr(vocab_parallel, "_device_logprob_entropy", _cpu_logprob_entropy)
+
+
 def install(monkeypatch):
     from dynamictreeattn_amd import ops, token_trie, tree_training_engine
     monkeypatch.setattr(token_trie, "_device_trie_arrays", _cpu_trie_arrays)

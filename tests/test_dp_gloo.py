@@ -146,7 +146,10 @@ def test_dp_with_an_empty_bin_still_reduces(overlapped):
 def _vp_worker(rank, world, port, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
+    sys.path.insert(0, os.path.dirname(__file__))
     from dynamictreeattn_amd import vocab_parallel as vp
+    import hostmirror
+    hostmirror.install_cpu_logprob()              # the product has no CPU path: host logits raise there
     _init(rank, world, port)
     gold = torch.load(os.path.join(GOLD, "logprob_cases.pt"), weights_only=True)
     out = {}
@@ -191,10 +194,17 @@ def test_vocab_parallel_matches_unsharded_and_reference():
     assert set(res[0]) == {"small", "temp"}
 
 
-def test_single_process_logprob_surface_and_shape_quirk():
-    """[1,B,V] logits with [1,B-1] labels (tte:190-193): logprobs B-1 rows, entropy B rows."""
+def test_single_process_logprob_surface_and_shape_quirk(monkeypatch):
+    """[1,B,V] logits with [1,B-1] labels (tte:190-193): logprobs B-1 rows, entropy B rows (the public surface's shape handling;
+    the arithmetic is the host stand-in here and the HIP kernels in tests/test_gpu_logprob.py)."""
     from dynamictreeattn_amd import vocab_parallel as vp
     from oracle import model_oracle as mo
+    import hostmirror
+    with pytest.raises(RuntimeError, match="no CPU path"):            # the product itself refuses host logits
+        vp.gather_logprobs(torch.randn(2, 8), torch.zeros(2, dtype=torch.long))
+    with pytest.raises(AssertionError):                               # vocab_parallel.py:46
+        vp.gather_logprobs(torch.zeros(0, 8), torch.zeros(0, dtype=torch.long))
+    hostmirror.install_cpu_logprob(monkeypatch)
     g = torch.Generator().manual_seed(0)
     logits = torch.randn(1, 9, 50, generator=g); labels = torch.randint(0, 50, (1, 8), generator=g)
     lp, ent = vp.gather_logprobs_entropy(logits, labels, chunk_size=4)

@@ -18,7 +18,13 @@ from oracle import model_oracle as mo
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 DEV = torch.device("cuda:0")
-REF_BF16_BOUND = 1.0636e-01          # grad/Qwen3-0.6B-TB-vs-DB-bf16.txt:6 (max |Δg|/|g| over 310 params)
+import json
+# the reference's recorded tree-vs-dense bf16 table (grad/Qwen3-0.6B-TB-vs-DB-bf16.txt) as data: scripts/make_golden.py formats
+RECORDED = json.load(open(os.path.join(GOLD, "recorded_bf16_table.json")))
+REF_BF16_BOUND = RECORDED["max"]                          # 1.0636e-01, model.layers.1.self_attn.q_norm.weight
+REF_BF16_MEDIAN = RECORDED["median"]                      # 2.55e-02
+REF_PARAM_NAMES = {r[0] for r in RECORDED["rows"]}        # the 310 parameters the reference compared
+assert abs(REF_BF16_BOUND - 1.0636e-01) < 1e-9 and abs(REF_BF16_MEDIAN - 2.55e-2) < 1e-4 and len(REF_PARAM_NAMES) == 310
 
 
 @pytest.fixture(scope="module")
@@ -61,7 +67,7 @@ def test_backward_bf16_vs_reference_fp32(name, perm, eng_gold):
     assert abs(loss - g["bwd_bs2048_loss"]) < 1e-2 * abs(loss)
     ratios = {n: mo.grad_ratio(g["bwd_bs2048_grads"][n], p.grad.float().cpu()) for n, p in m.named_parameters()}
     assert max(ratios.values()) <= REF_BF16_BOUND, max(ratios.items(), key=lambda kv: kv[1])
-    assert float(np.median(list(ratios.values()))) <= 2.55e-2
+    assert float(np.median(list(ratios.values()))) <= REF_BF16_MEDIAN
 
 
 @pytest.mark.parametrize("name", ["d128_minitau", "d128_tree"])
@@ -75,7 +81,7 @@ def test_tree_equals_dense_on_gpu(name):
     ld = dense.backward(m, seqs, _att(len(seqs)), mo.default_loss)
     assert abs(lt - ld) < 5e-3 * abs(ld)
     ratios = [mo.grad_ratio(p.grad.float(), gt[n]) for n, p in m.named_parameters()]
-    assert max(ratios) <= REF_BF16_BOUND and float(np.median(ratios)) <= 2.55e-2
+    assert max(ratios) <= REF_BF16_BOUND and float(np.median(ratios)) <= REF_BF16_MEDIAN
     lps = dense.forward(m, seqs)
     t2 = TokenTrie(seqs); t2.forward_permute()
     out = TreeTrainingEngine(m.config, DEV, torch.bfloat16, max(map(len, seqs)), forward_only=True).forward(m, t2)
@@ -162,10 +168,10 @@ def test_qwen3_0p6b_config1_tree_vs_dense_within_recorded_bound():
     m.zero_grad(set_to_none=True)
     ld = dense.backward(m, seqs, att(), mo.default_loss)
     ratios = {n: mo.grad_ratio(p.grad.float(), gt[n]) for n, p in m.named_parameters()}
-    assert len(ratios) == 310
+    assert set(ratios) == REF_PARAM_NAMES                  # the same 310 tensors the reference's table lists
     worst = max(ratios.items(), key=lambda kv: kv[1])
     assert worst[1] <= REF_BF16_BOUND, worst
-    assert float(np.median(list(ratios.values()))) <= 2.55e-2
+    assert float(np.median(list(ratios.values()))) <= REF_BF16_MEDIAN
     assert abs(lt - ld) < 2e-3 * abs(ld)
     path = os.path.join(GOLD, "qwen3_0p6b_config1.json")
     if os.path.exists(path):
@@ -194,11 +200,11 @@ def test_qwen3_0p6b_full_tau2_call_tree_vs_dense_within_recorded_bound():
     m.zero_grad(set_to_none=True)
     ld = dense.backward(m, seqs, att(), mo.default_loss)
     ratios = {n: mo.grad_ratio(p.grad.float(), gt[n]) for n, p in m.named_parameters()}
-    assert len(ratios) == 310
+    assert set(ratios) == REF_PARAM_NAMES                  # the same 310 tensors the reference's table lists
     worst = max(ratios.items(), key=lambda kv: kv[1])
     print(f"full tau2 call: loss tree {lt:.6f} dense {ld:.6f}; worst |dg|/|g| {worst[1]:.4e} ({worst[0]}), median {float(np.median(list(ratios.values()))):.4e}")
     assert worst[1] <= REF_BF16_BOUND, worst
-    assert float(np.median(list(ratios.values()))) <= 2.55e-2
+    assert float(np.median(list(ratios.values()))) <= REF_BF16_MEDIAN
     assert abs(lt - ld) < 2e-3 * abs(ld)
 
 
@@ -267,8 +273,82 @@ def test_qwen3_0p6b_full_tau2_call_blockwise_walk_equals_one_pass():
     print(f"full tau2 call: loss packed {out['packed'][0]:.6f} stack {out['stack'][0]:.6f}; worst |dg|/|g| {worst[1]:.4e} ({worst[0]}), "
           f"median {float(np.median(list(ratios.values()))):.4e}")
     assert worst[1] <= REF_BF16_BOUND, worst
-    assert float(np.median(list(ratios.values()))) <= 2.55e-2
+    assert float(np.median(list(ratios.values()))) <= REF_BF16_MEDIAN
     assert abs(out["packed"][0] - out["stack"][0]) < 2e-3 * abs(out["packed"][0])
+
+
+@pytest.mark.parametrize("family", ["qwen3", "qwen2"])
+def test_unmodified_huggingface_model_through_the_engine_on_the_gpu(family, eng_gold):
+    """The drop-in claim of INTEGRATION.md (the reference loads an HF `*ForCausalLM` and hands it to the engine, run.py:199-204,
+    79-114): an UNMODIFIED `transformers.Qwen3ForCausalLM` / `Qwen2ForCausalLM` (q/k/v biases, no q/k norm) on `cuda`, bf16, goes
+    through `TreeTrainingEngine.forward` and `.backward` on the HIP kernels; results against what the REFERENCE engine produced
+    with the same HF class in fp32 (tests/golden/engine_tiny.pt, engine_qwen2_tiny.pt; scripts/make_golden.py).  Gradients land on
+    the HF module's own nn.Parameters."""
+    pytest.importorskip("transformers")
+    if family == "qwen3":
+        case = cases.engine_cases()["d128_minitau"]; cfg = cases.TINY_CFGS[case["cfg"]]
+        hf = cases.hf_qwen3(cfg, mo.init_weights(cfg, seed=case["wseed"]))
+        seqs = synth.as_tensors(synth.make_case(case["data"])); g = eng_gold["d128_minitau"]
+        gold_grads = g["bwd_bs2048_grads"]
+    else:
+        hf = cases.hf_qwen2()
+        seqs = synth.as_tensors(synth.make_case(cases.QWEN2_DATA))
+        g = torch.load(os.path.join(GOLD, "engine_qwen2_tiny.pt"), weights_only=True)
+        gold_grads = {n: q.float() * s_ for n, (q, s_) in g["bwd_bs2048_grads_fp16_scaled"].items()}
+        assert any(n.endswith("k_proj.bias") for n in gold_grads) and not any("q_norm" in n for n in gold_grads)
+    hf = hf.to(device=DEV, dtype=torch.bfloat16).train()
+    assert type(hf).__module__.startswith("transformers.")
+    maxlen = max(map(len, seqs))
+    t = TokenTrie(seqs); t.forward_permute()
+    out = TreeTrainingEngine(hf.config, DEV, torch.bfloat16, maxlen, forward_only=True).forward(hf, t)
+    for a, b in zip(out, g["fwd_forward"]):
+        assert a.dtype == torch.float32 and a.shape == b.shape
+        assert (a.cpu() - b).abs().max() < 0.08 and (a.cpu() - b).abs().mean() < 0.015
+    t = TokenTrie(seqs, _att(len(seqs))); t.backward_permute()
+    loss = TreeTrainingEngine(hf.config, DEV, torch.bfloat16, maxlen).backward(hf, t, mo.default_loss, 2048)
+    assert abs(loss - g["bwd_bs2048_loss"]) < 1e-2 * abs(loss)
+    named = dict(hf.named_parameters())
+    assert set(gold_grads) <= set(named)
+    ratios = {n: mo.grad_ratio(gold_grads[n], named[n].grad.float().cpu()) for n in gold_grads}
+    assert max(ratios.values()) <= REF_BF16_BOUND, max(ratios.items(), key=lambda kv: kv[1])
+    assert float(np.median(list(ratios.values()))) <= REF_BF16_MEDIAN
+    # the block-wise walk takes the same module
+    hf.zero_grad(set_to_none=True)
+    e = TreeTrainingEngine(hf.config, DEV, torch.bfloat16, maxlen); e.mode = "stack"
+    t = TokenTrie(seqs, _att(len(seqs))); t.backward_permute()
+    loss_s = e.backward(hf, t, mo.default_loss, 16)
+    assert abs(loss_s - g["bwd_bs2048_loss"]) < 1e-2 * abs(loss)
+    worst = max(mo.grad_ratio(gold_grads[n], named[n].grad.float().cpu()) for n in gold_grads)
+    assert worst <= REF_BF16_BOUND, worst
+
+
+def test_tokentrie_from_gpu_resident_token_ids():
+    """The reference's TokenTrie takes tensors on any device (token_trie.py:51-82): ids already on the GPU need no host staging."""
+    seqs = synth.as_tensors(synth.make_case(cases.engine_cases()["d128_tree"]["data"]))
+    a = TokenTrie(seqs); b = TokenTrie([s.to(DEV) for s in seqs])
+    assert a.lens == b.lens and a.lcp_lens == b.lcp_lens and torch.equal(a._dev.tokens, b._dev.tokens)
+    assert [[(x["_sequence_batch_id"], n) for x, n in al] for al in a.attach_lists] == [[(x["_sequence_batch_id"], n) for x, n in al] for al in b.attach_lists]
+
+
+def test_measured_recomputation_plan_runs_and_changes_nothing(monkeypatch):
+    """The CALLABLE layer plan (`_full_layers` -> plan(bytes kept by layer 0), model.py `packed_hidden_states`): with the free-HBM
+    reading shrunk so that the automatic decision recomputes, layer 0 runs in full, is measured, and the plan keeps as many leading
+    layers as its budget (which already leaves the attention-keep promise and the per-layer stashes alone) allows.  Same loss and
+    gradients as the plain pass, bit for bit."""
+    m, seqs = _setup("d128_minitau", torch.bfloat16)
+    att = lambda: [{"w_logprobs": -1.0, "w_entropy": 0.1} for _ in seqs]
+    res = []
+    for small in (False, True):
+        m.zero_grad(set_to_none=True)
+        t = TokenTrie(seqs, att()); t.backward_permute()
+        e = TreeTrainingEngine(m.config, DEV, torch.bfloat16, max(map(len, seqs)))
+        e.mode = "packed"
+        if small:
+            monkeypatch.setattr(e, "_free_hbm", lambda: 200_000)       # bytes: far below one layer's activations of this trie
+        loss = e.backward(m, t, mo.default_loss, 64)
+        res.append((loss, e.last_mode, {n: p.grad.clone() for n, p in m.named_parameters()}))
+    assert res[0][1] == "packed" and res[1][1].startswith("packed+recompute["), res[1][1]
+    assert res[0][0] == res[1][0] and all(torch.equal(res[0][2][n], res[1][2][n]) for n in res[0][2])
 
 
 def test_hf_attention_interface_plugin_matches_eager():
@@ -341,7 +421,7 @@ def test_blockwise_stack_engine_bf16_vs_reference_fp32(name, bs, eng_gold):
     assert abs(loss - g["bwd_bs2048_loss"]) < 1e-2 * abs(loss)
     ratios = {n: mo.grad_ratio(g["bwd_bs2048_grads"][n], p.grad.float().cpu()) for n, p in m.named_parameters()}
     assert max(ratios.values()) <= REF_BF16_BOUND, max(ratios.items(), key=lambda kv: kv[1])
-    assert float(np.median(list(ratios.values()))) <= 2.55e-2
+    assert float(np.median(list(ratios.values()))) <= REF_BF16_MEDIAN
 
 
 QWEN3_4B_LAYER = dict(vocab_size=151936, hidden_size=2560, intermediate_size=9728, num_hidden_layers=2, num_attention_heads=32,
@@ -376,6 +456,6 @@ def test_blockwise_engine_bounds_activation_memory_at_qwen3_4b_geometry():
     assert abs(l0 - l1) < 3e-3 * abs(l0)
     ratios = {n: mo.grad_ratio(g0[n], p.grad.float()) for n, p in m.named_parameters()}
     assert max(ratios.values()) <= REF_BF16_BOUND, max(ratios.items(), key=lambda kv: kv[1])
-    assert float(np.median(list(ratios.values()))) <= 2.55e-2
+    assert float(np.median(list(ratios.values()))) <= REF_BF16_MEDIAN
     assert peak_stack < 0.5 * peak_packed, (peak_stack, peak_packed)
     print(f"peak activation memory: one pass {peak_packed / 2**30:.2f} GiB, block-wise ({e.last_mode}) {peak_stack / 2**30:.2f} GiB")

@@ -99,6 +99,25 @@ def test_balancers_bit_exact(balancer_golden):
                 assert dp.get_original_bins(tt, lb) == exp["LB_by_DFS_and_TM"], (item["case"], key)
 
 
+def test_random_orders_under_a_seeded_global_rng():
+    """`--permute random` (run.py:93-94 -> token_trie.py:106-109) uses `seed=None`: the global RNG is consumed in the reference's node
+    order, so a seeded run reproduces the reference's leaf order bit for bit (tests/golden/random_order_cases.json)."""
+    import json, random
+    gold = json.load(open(os.path.join(GOLD, "random_order_cases.json")))
+    for item in gold["cases"]:
+        seqs = synth.as_tensors(synth.make_case(item["case"]))
+        t = TokenTrie(seqs, device=CPU)
+        for k, exp in item["orders"].items():
+            random.seed(int(k))
+            assert CompressedTrie(t.lens, t.lcp_lens).get_order_random() == exp, (item["case"], k)
+            t2 = TokenTrie(seqs, device=CPU); random.seed(int(k)); t2.random_permute()
+            assert t2.lens == item["permuted"][k]["lens"] and t2.lcp_lens == item["permuted"][k]["lcp_lens"]
+    p = gold["probe"]
+    for k, exp in p["orders"].items():
+        random.seed(int(k))
+        assert CompressedTrie(p["lens"], p["lcp"]).get_order_random() == exp, k
+
+
 def test_public_balancer_entries_bit_exact(balancer_golden, monkeypatch):
     """The PUBLIC entries LB_by_n_tokens / LB_by_TM / LB_by_DFS_and_TM(seqs, tm, args) (data_parallel.py:8-16, 39-56, 81-107) against
     the reference's recorded bins.  They build their own TokenTrie; here its device steps are the CPU stand-ins (the same entries
@@ -336,6 +355,26 @@ def test_engine_accepts_a_huggingface_module_by_duck_typing(eng_gold):
             assert mo.grad_ratio(g["bwd_bs2048_grads"][n], p.grad) <= 2e-5, n
 
 
+def test_engine_accepts_a_huggingface_qwen2_module_with_biases():
+    """Qwen2ForCausalLM (q/k/v biases, no per-head q/k norm) through the engine vs the REFERENCE engine on the same class
+    (tests/golden/engine_qwen2_tiny.pt): loss and all 26 gradients, fp32 on the CPU stand-ins."""
+    pytest.importorskip("transformers")
+    hf = cases.hf_qwen2()
+    g = torch.load(os.path.join(GOLD, "engine_qwen2_tiny.pt"), weights_only=True)
+    seqs = synth.as_tensors(synth.make_case(cases.QWEN2_DATA))
+    t = TokenTrie(seqs, device=CPU); t.forward_permute()
+    out = TreeTrainingEngine(hf.config, CPU, torch.float32, 64, forward_only=True).forward(hf, t)
+    for a, b in zip(out, g["fwd_forward"]):
+        assert torch.allclose(a, b, atol=2e-5)
+    t = TokenTrie(seqs, _att(len(seqs)), device=CPU); t.backward_permute()
+    loss = TreeTrainingEngine(hf.config, CPU, torch.float32, 64).backward(hf, t, mo.default_loss, 2048)
+    assert abs(loss - g["bwd_bs2048_loss"]) < 2e-5 * abs(loss)
+    named = dict(hf.named_parameters())
+    for n, (q, s_) in g["bwd_bs2048_grads_fp16_scaled"].items():
+        assert mo.grad_ratio(q.float() * s_, named[n].grad) <= 1e-3, n                        # fp16-packed golden: 5e-4 per element
+        assert abs(float(named[n].grad.norm()) - g["grad_norms"][n]) <= 2e-5 * g["grad_norms"][n] + 1e-9, n
+
+
 def test_dkv_work_units_partition_every_key_tile():
     """packing.plan_dkv_units: the units of a key tile tile its query range exactly, in 64-row multiples,
     split tiles get consecutive slabs listed in `splits`, heaviest units first."""
@@ -363,3 +402,40 @@ def test_dkv_work_units_partition_every_key_tile():
             else:
                 assert u[0, 3] == -1
         assert sorted(slabs_seen) == list(range(n_slabs))
+
+
+def test_grad_reducer_start_after_a_foreign_zero_grad_does_not_keep_stale_sums():
+    """`optimizer.zero_grad()` (set_to_none) -> `red.start()` -> backward: the flat buffers still hold the previous step's reduced
+    sums when start() re-attaches the views; they must be zeroed, or step 2 accumulates onto step 1 (2.0 where 1.0 is expected)."""
+    from dynamictreeattn_amd import dp as dpr
+    m = torch.nn.Linear(4, 3)
+    red = dpr.GradReducer(m.parameters(), overlap=False)
+    x = torch.ones(2, 4)
+    red.zero_grad(); red.start(); m(x).sum().backward()
+    g1 = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad(set_to_none=True)
+    red.start(); m(x).sum().backward()
+    views = {id(p): v for p, v in red._views}
+    for p, g in zip(m.parameters(), g1):
+        assert p.grad.data_ptr() == views[id(p)].data_ptr() and torch.equal(p.grad, g)
+    dpr._ACTIVE.discard(red)
+
+
+def test_loss_fn_may_return_a_plain_number_for_some_sequences(monkeypatch):
+    """The reference sums `loss += loss_fn(...)` from 0.0 (tte:396-398), so a callback returning a Python number for some sequence
+    works there; it must here too (packed and block-wise)."""
+    case = cases.engine_cases()["d16_tree"]; cfg = cases.TINY_CFGS[case["cfg"]]
+    from dynamictreeattn_amd.model import Qwen3TreeLM
+    seqs = synth.as_tensors(synth.make_case(case["data"]))
+    fn = lambda lp, ent, att: (0.25 if att["_sequence_batch_id"] % 2 else mo.default_loss(lp, ent, att))
+    ref = None
+    for mode in ("packed", "stack"):
+        model = Qwen3TreeLM(cfg).load_named(mo.init_weights(cfg, seed=case["wseed"]))
+        t = TokenTrie(seqs, [{"w_logprobs": -1.0, "w_entropy": 0.1} for _ in seqs], device=CPU); t.backward_permute()
+        e = TreeTrainingEngine(model.config, "cpu", torch.float32, 4096); e.mode = mode
+        loss = e.backward(model, t, fn, 16)
+        n_odd = sum(1 for i in range(len(seqs)) if i % 2)
+        full = TreeTrainingEngine(model.config, "cpu", torch.float32, 4096)
+        if ref is None:
+            ref = loss
+        assert abs(loss - ref) < 1e-4 * abs(ref) and n_odd > 0
