@@ -206,10 +206,15 @@ def main():
     if 0 < n_dev < world:                       # shared card: cap every rank's caching allocator at its share of the HBM; the engine's
         share = (n_dev * 0.92) / world          # footprint decisions (ops.free_hbm) honour the cap, so no rank plans with the whole card
         torch.cuda.set_per_process_memory_fraction(share, dev)
+    elif os.environ.get("DTA_BENCH_HBM_FRACTION"):          # diagnostic: independent processes sharing one card, each under its own cap
+        torch.cuda.set_per_process_memory_fraction(float(os.environ["DTA_BENCH_HBM_FRACTION"]), dev)
     if world > 1:
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     note(rank, f"world {world}, backend {backend}, device {dev}")
+    if os.environ.get("DTA_BENCH_WATCHDOG"):        # diagnostic: every rank dumps its Python stacks to stderr if it is still running after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["DTA_BENCH_WATCHDOG"]), repeat=False, file=sys.stderr)
     dtype = torch.float16 if wide else torch.bfloat16                     # BASELINE config 5 is fp16
     cfg = MODEL_CFG[args.model]
     model = build_model(cfg, dev, dtype)
@@ -231,7 +236,12 @@ def main():
     # overlapped with the backward.  DTA_BENCH_OVERLAP=0 reduces after the backward instead.
     reducer = None
     if world > 1 and not tp:
-        reducer = dp.GradReducer(model.parameters(), overlap=os.environ.get("DTA_BENCH_OVERLAP", "1") == "1")
+        # one-card rehearsals (gloo, ranks sharing the GPU) reduce after the backward by default: with 3+ ranks on one card the
+        # hook-launched asynchronous gloo all-reduces (host-staged copies of the CUDA buckets, issued while every rank's backward
+        # kernels are still queued on the same GPU) stall the step for minutes, while the same reduce issued after the backward
+        # runs at the 4-way time-sliced rate (gpurun records r3/bench_n4_gloo*.err).  RCCL always overlaps.
+        shared_card = 0 < n_dev < world
+        reducer = dp.GradReducer(model.parameters(), overlap=os.environ.get("DTA_BENCH_OVERLAP", "0" if (shared_card and backend == "gloo") else "1") == "1")
 
     def zero():
         if reducer is not None:
@@ -269,6 +279,9 @@ def main():
         for b in batches:
             step(b, acc)                 # ends with the engine's loss.item(): the step's own work is done when it returns
             marks.append(time.time())
+            if world > 1 and os.environ.get("DTA_BENCH_WATCHDOG"):
+                print(f"[bench +{time.time() - T_START:6.1f}s] rank {rank}: step done in {marks[-1] - (marks[-2] if len(marks) > 1 else t0):.2f}s, mode {engine.last_mode}, "
+                      f"reserved {torch.cuda.memory_reserved(dev) / 1e9:.1f} GB", file=sys.stderr, flush=True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
