@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("DTA_LIB") or os.path.join(HERE, "libdta_mi355x.so")      # DTA_LIB: diagnostic builds only
-SOURCES = ["tree_attn.hip", "trie_kernels.hip", "logprob_kernels.hip", "elementwise_kernels.hip"]
+SOURCES = ["tree_attn.hip", "tree_attn_f32.hip", "trie_kernels.hip", "logprob_kernels.hip", "elementwise_kernels.hip"]
 
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17"]

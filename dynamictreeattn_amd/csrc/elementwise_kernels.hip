@@ -16,6 +16,11 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 template <int DT> struct ETy;
 template <> struct ETy<DTA_BF16> { using e = __bf16; using v8 = bf16x8; };
 template <> struct ETy<DTA_F16> { using e = _Float16; using v8 = f16x8; };
+// fp32 models (the reference's --dtype fp32, run.py:122-132): same kernels, 8 floats = two 16-byte accesses per lane; the
+// roundings to the storage type `(e)(...)` are then the identity
+typedef float f32x8 __attribute__((ext_vector_type(8), aligned(16)));
+template <> struct ETy<DTA_F32> { using e = float; using v8 = f32x8; };
+inline bool row_dtype_ok(int dtype) { return dtype == DTA_BF16 || dtype == DTA_F16 || dtype == DTA_F32; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -297,13 +302,14 @@ inline int row_blocks(int64_t rows, int per_block, int cap) { int64_t b = (rows 
 #define DTA_DISPATCH(KERNEL, GRID, ...)                                                                    \
   do { hipStream_t st_ = static_cast<hipStream_t>(stream); DTA_REFUSE_IF_PRIOR_ERROR();                    \
        if (dtype == DTA_BF16) hipLaunchKernelGGL(KERNEL<DTA_BF16>, dim3(GRID), dim3(256), 0, st_, __VA_ARGS__); \
-       else hipLaunchKernelGGL(KERNEL<DTA_F16>, dim3(GRID), dim3(256), 0, st_, __VA_ARGS__);               \
+       else if (dtype == DTA_F16) hipLaunchKernelGGL(KERNEL<DTA_F16>, dim3(GRID), dim3(256), 0, st_, __VA_ARGS__); \
+       else hipLaunchKernelGGL(KERNEL<DTA_F32>, dim3(GRID), dim3(256), 0, st_, __VA_ARGS__);               \
        return DTA_LAUNCH_STATUS(); } while (0)
 
 extern "C" int dta_rmsnorm_fwd(const void* x, const void* delta, const void* w, void* x_out, void* y, float* rstd,
                                int32_t R, int32_t H, float eps, int32_t dtype, void* stream) {
   if (!x || !w || !y || !rstd || R <= 0 || H <= 0 || ((delta != nullptr) != (x_out != nullptr))) return DTA_EINVAL;
-  if ((dtype != DTA_BF16 && dtype != DTA_F16) || H % 8) return DTA_EUNSUPPORTED;
+  if (!row_dtype_ok(dtype) || H % 8) return DTA_EUNSUPPORTED;
   if (!al16(x) || !al16(w) || !al16(y) || (delta && (!al16(delta) || !al16(x_out)))) return DTA_EALIGN;
   DTA_DISPATCH(rmsnorm_fwd_kernel, row_blocks(R, 4, 4096), x, delta, w, x_out, y, rstd, R, H, eps);
 }
@@ -313,17 +319,19 @@ extern "C" int dta_rmsnorm_bwd_blocks(int32_t R) { return row_blocks(R, 4, 2048)
 extern "C" int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, const void* dres, const float* rstd, void* dx, float* dw_partial,
                                int32_t R, int32_t H, int32_t dtype, void* stream) {
   if (!x || !w || !dy || !rstd || !dx || !dw_partial || R <= 0 || H <= 0) return DTA_EINVAL;
-  if ((dtype != DTA_BF16 && dtype != DTA_F16) || H % 8 || H > 8192) return DTA_EUNSUPPORTED;
+  if (!row_dtype_ok(dtype) || H % 8 || H > 8192) return DTA_EUNSUPPORTED;
   if (!al16(x) || !al16(w) || !al16(dy) || !al16(dx) || (dres && !al16(dres))) return DTA_EALIGN;
   hipStream_t st_ = static_cast<hipStream_t>(stream);
   DTA_REFUSE_IF_PRIOR_ERROR();
   const dim3 grid(row_blocks(R, 4, 2048)), block(256);
   if (H <= 4096) {
     if (dtype == DTA_BF16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_BF16, 8>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
-    else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F16, 8>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
+    else if (dtype == DTA_F16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F16, 8>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
+    else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F32, 8>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
   } else {
     if (dtype == DTA_BF16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_BF16, 16>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
-    else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F16, 16>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
+    else if (dtype == DTA_F16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F16, 16>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
+    else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F32, 16>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
   }
   return DTA_LAUNCH_STATUS();
 }
@@ -331,7 +339,7 @@ extern "C" int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, con
 extern "C" int dta_qk_norm_rope_fwd(const void* x, const void* w, const float* cos_sin, void* y, float* rstd,
                                     int32_t T, int32_t NH, int32_t head_dim, int64_t x_stride_t, float eps, int32_t dtype, void* stream) {
   if (!x || !cos_sin || !y || T <= 0 || NH <= 0 || (w && !rstd)) return DTA_EINVAL;
-  if ((dtype != DTA_BF16 && dtype != DTA_F16) || head_dim != 128) return DTA_EUNSUPPORTED;
+  if (!row_dtype_ok(dtype) || head_dim != 128) return DTA_EUNSUPPORTED;
   if (!al16(x) || !al16(y) || (w && !al16(w)) || x_stride_t % 8) return DTA_EALIGN;
   const int64_t n = (int64_t)T * NH;
   DTA_DISPATCH(qk_norm_rope_fwd_kernel, (unsigned)((n + 15) / 16), x, w, cos_sin, y, rstd, n, NH, x_stride_t, eps);
@@ -343,7 +351,7 @@ extern "C" int dta_qk_norm_rope_bwd(const void* x, const void* w, const float* c
                                     void* dx, float* dw_partial, int32_t T, int32_t NH, int32_t head_dim,
                                     int64_t x_stride_t, int64_t dy_stride_t, int64_t dy_stride_h, int64_t dx_stride_t, int32_t dtype, void* stream) {
   if (!cos_sin || !dy || !dx || T <= 0 || NH <= 0 || (w && (!x || !rstd || !dw_partial))) return DTA_EINVAL;
-  if ((dtype != DTA_BF16 && dtype != DTA_F16) || head_dim != 128) return DTA_EUNSUPPORTED;
+  if (!row_dtype_ok(dtype) || head_dim != 128) return DTA_EUNSUPPORTED;
   if (!al16(dy) || !al16(dx) || (w && (!al16(w) || !al16(x))) || x_stride_t % 8 || dy_stride_t % 8 || dy_stride_h % 8 || dx_stride_t % 8) return DTA_EALIGN;
   if (dx_stride_t < (int64_t)NH * 128) return DTA_EINVAL;
   const int64_t n = (int64_t)T * NH;
@@ -352,7 +360,7 @@ extern "C" int dta_qk_norm_rope_bwd(const void* x, const void* w, const float* c
 
 extern "C" int dta_swiglu_fwd(const void* gate, const void* up, void* y, int64_t rows, int32_t cols, int64_t ld, int32_t dtype, void* stream) {
   if (!gate || !up || !y || rows <= 0 || cols <= 0 || ld < cols) return DTA_EINVAL;
-  if ((dtype != DTA_BF16 && dtype != DTA_F16) || cols % 8 || ld % 8) return DTA_EUNSUPPORTED;
+  if (!row_dtype_ok(dtype) || cols % 8 || ld % 8) return DTA_EUNSUPPORTED;
   if (!al16(gate) || !al16(up) || !al16(y)) return DTA_EALIGN;
   const int64_t n8 = rows * (cols / 8);
   DTA_DISPATCH(swiglu_fwd_kernel, row_blocks(n8, 256, 4096), gate, up, y, n8, cols / 8, ld);
@@ -361,7 +369,7 @@ extern "C" int dta_swiglu_fwd(const void* gate, const void* up, void* y, int64_t
 extern "C" int dta_swiglu_bwd(const void* gate, const void* up, const void* dy, void* dgate, void* dup,
                               int64_t rows, int32_t cols, int64_t ld, int64_t ld_grad, int32_t dtype, void* stream) {
   if (!gate || !up || !dy || !dgate || !dup || rows <= 0 || cols <= 0 || ld < cols || ld_grad < cols) return DTA_EINVAL;
-  if ((dtype != DTA_BF16 && dtype != DTA_F16) || cols % 8 || ld % 8 || ld_grad % 8) return DTA_EUNSUPPORTED;
+  if (!row_dtype_ok(dtype) || cols % 8 || ld % 8 || ld_grad % 8) return DTA_EUNSUPPORTED;
   if (!al16(gate) || !al16(up) || !al16(dy) || !al16(dgate) || !al16(dup)) return DTA_EALIGN;
   const int64_t n8 = rows * (cols / 8);
   DTA_DISPATCH(swiglu_bwd_kernel, row_blocks(n8, 256, 4096), gate, up, dy, dgate, dup, n8, cols / 8, ld, ld_grad);

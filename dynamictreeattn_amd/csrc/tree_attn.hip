@@ -816,8 +816,13 @@ extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v,
                                     float scale, int32_t dtype, void* stream) {
   if (!q || !k || !v || !out || !lse || Tq <= 0 || Tk <= 0 || Hq <= 0 || Hkv <= 0 || q_offset < 0) return DTA_EINVAL;
   if ((runs == nullptr) != (run_ptr == nullptr)) return DTA_EINVAL;
-  if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16)) return DTA_EUNSUPPORTED;
+  if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16 && dtype != DTA_F32)) return DTA_EUNSUPPORTED;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || (q_st | q_sh | kv_st | kv_sh | v_st | v_sh | o_st | o_sh) % 8 != 0) return DTA_EALIGN;
+  if (dtype == DTA_F32) {                                    // fp32 models: the plain-FMA correctness path (tree_attn_f32.hip)
+    DTA_REFUSE_IF_PRIOR_ERROR();
+    return dta_attn_fwd_f32(q, k, v, out, lse, subtree_end, run_ptr, runs, Tq, Tk, q_offset, Hq, Hkv, q_st, q_sh, kv_st, kv_sh, v_st, v_sh, o_st, o_sh,
+                            scale, static_cast<hipStream_t>(stream));
+  }
   // the tile DMA addresses a 64-row tile as scalar base + 32-bit lane offset: token strides must keep 64 rows inside 4 GiB
   if (kv_st < 0 || v_st < 0 || kv_st > (1 << 24) || v_st > (1 << 24)) return DTA_EUNSUPPORTED;
   AttnParams p{};
@@ -858,9 +863,16 @@ extern "C" int dta_tree_attn_bwd_ex(const void* q, const void* k, const void* v,
   if (!q || !k || !v || !out || !dout || !lse || !delta || !dq || !dk || !dv || Tq <= 0 || Tk <= 0 || Hq <= 0 || Hkv <= 0 || q_offset < 0) return DTA_EINVAL;
   if ((runs == nullptr) != (run_ptr == nullptr)) return DTA_EINVAL;
   if (dkv_units && (n_units <= 0 || n_splits < 0 || (n_splits > 0 && (!dkv_splits || !dkv_ws)))) return DTA_EINVAL;
-  if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16) || accumulate < 0 || accumulate > 2) return DTA_EUNSUPPORTED;
+  if (head_dim != 128 || Hq % Hkv != 0 || (dtype != DTA_BF16 && dtype != DTA_F16 && dtype != DTA_F32) || accumulate < 0 || accumulate > 2) return DTA_EUNSUPPORTED;
   if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) ||
       (q_st | q_sh | kv_st | kv_sh | v_st | v_sh | o_st | o_sh | dq_st | dq_sh | dkv_st | dkv_sh) % 8 != 0) return DTA_EALIGN;
+  if (dtype == DTA_F32) {
+    if ((which & 7) == 0) return DTA_EINVAL;
+    DTA_REFUSE_IF_PRIOR_ERROR();
+    return dta_attn_bwd_f32(q, k, v, out, dout, lse, delta, dq, dk, dv, subtree_end, run_ptr, runs, ktile_qend, Tq, Tk, q_offset, Hq, Hkv,
+                            q_st, q_sh, kv_st, kv_sh, v_st, v_sh, o_st, o_sh, dq_st, dq_sh, dkv_st, dkv_sh, scale, accumulate, which,
+                            static_cast<hipStream_t>(stream));
+  }
   if (q_st < 0 || o_st < 0 || q_st > (1 << 24) || o_st > (1 << 24)) return DTA_EUNSUPPORTED;   // 64-row tile = scalar base + 32-bit lane offset
   AttnParams p{};
   p.q = q; p.k = k; p.v = v; p.o = out; p.dout = dout; p.lse_r = lse; p.delta = delta; p.dq = dq; p.dk = dk; p.dv = dv;

@@ -182,17 +182,18 @@ class _LayerRecompute(torch.autograd.Function):
 
 
 def packed_hidden_states(model, tokens: torch.Tensor, depth: torch.Tensor, meta, checkpoint_layers: bool = False,
-                         attn_keep_bytes: int = 0, attn_of_layer=None, full_layers=0, kept_out=None) -> torch.Tensor:
+                         attn_keep_bytes: int = 0, attn_of_layer=None, full_layers=0, kept_out=None, embed=None) -> torch.Tensor:
     """Final-norm hidden states [T, hidden] of the packed tokens.  `model` is a Qwen3TreeLM or an HF
     Qwen2/Qwen3 *ForCausalLM (duck-typed).  `checkpoint_layers`: recompute each layer in the backward, except the first
     `full_layers`, which keep their activations like the plain pass — an int, or a plan `bytes kept by layer 0 -> number of
     layers` that is asked once layer 0 has run in full and its footprint has been measured (the number lands in `kept_out`);
     `attn_keep_bytes`: HBM budget for attention outputs kept across that recomputation (layers are served first to last).
     `attn_of_layer(l)` -> callable (q, k, v) -> o replaces the packed tree attention (the block-wise engine passes the
-    stack form bound to layer l's KV stack; `meta` is unused then)."""
+    stack form bound to layer l's KV stack; `meta` is unused then); `embed(tokens)` replaces the plain embedding lookup (the
+    block-wise engine routes the rows' gradients into its fp32 sink instead of a dense [vocab, hidden] gradient per block)."""
     Hq, Hkv, D, eps, theta = _cfg_of(model)
     body = model.model
-    res, delta = F.embedding(tokens, body.embed_tokens.weight), None
+    res, delta = (embed(tokens) if embed is not None else F.embedding(tokens, body.embed_tokens.weight)), None
     cos_sin = ops.rope_cos_sin(depth, D, theta)
     per_layer = tokens.shape[0] * Hq * (D * res.element_size() + 4)             # out + lse of one layer
     n_full = full_layers if isinstance(full_layers, int) else 1

@@ -11,8 +11,9 @@ import torch.nn.functional as F
 from . import packing
 from ._lib import check, lib, ptr
 
-_DT = {torch.bfloat16: 0, torch.float16: 1}
-_DT_LOGITS = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}      # DTA_F32: log-prob / entropy kernels only
+# DTA_BF16 / DTA_F16: the MFMA kernels; DTA_F32: fp32 models (plain-FMA attention of tree_attn_f32.hip, fp32 row kernels)
+_DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+_DT_LOGITS = _DT
 
 
 class _on:
@@ -166,6 +167,8 @@ def attn_bwd_raw(q, k, v, out, dout, lse, meta: TreeAttnMeta, scale: float, dk=N
     units, splits = meta.dkv_units, meta.dkv_splits
     n_units = units.shape[0] if units is not None else 0
     n_splits = splits.shape[0] if splits is not None else 0
+    if q.dtype == torch.float32:            # the fp32 path sweeps one key block per workgroup: no split-Q units, no slabs
+        units = splits = None; n_units = n_splits = 0
     ws = torch.empty((meta.n_slabs, Hkv, 2, packing.KTILE, D), dtype=torch.float32, device=q.device) if (units is not None and meta.n_slabs) else None
 
     def launch(which, stream):
@@ -262,7 +265,7 @@ def stack_attention(q, k_new, v_new, kst, vst, gk, gv, start: int, scale: Option
     """q [B,Hq,128], k_new/v_new [B,Hkv,128] at stack positions start..start+B-1; kst/vst [cap,Hkv,128] (model dtype),
     gk/gv [cap,Hkv,128] fp32 grad stacks (may be None under no_grad) -> out [B,Hq,128]."""
     if q.dtype not in _DT:
-        raise TypeError("stack_attention supports bf16 / f16 (got %s)" % q.dtype)
+        raise TypeError("stack_attention supports bf16 / f16 / f32 (got %s)" % q.dtype)
     scale = q.shape[-1] ** -0.5 if scale is None else scale
     return _StackAttention.apply(q, k_new, v_new, kst, vst, gk, gv, start, scale)
 
@@ -270,7 +273,7 @@ def stack_attention(q, k_new, v_new, kst, vst, gk, gv, start: int, scale: Option
 def tree_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, meta: TreeAttnMeta, scale: Optional[float] = None) -> torch.Tensor:
     """q [T,Hq,128], k/v [T,Hkv,128] packed in DFS pre-order -> out [T,Hq,128].  Differentiable."""
     if q.dtype not in _DT:
-        raise TypeError("tree_attention supports bf16 / f16 (got %s)" % q.dtype)
+        raise TypeError("tree_attention supports bf16 / f16 / f32 (got %s)" % q.dtype)
     scale = q.shape[-1] ** -0.5 if scale is None else scale
     return _TreeAttention.apply(q, k, v, meta, scale)
 

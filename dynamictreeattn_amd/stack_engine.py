@@ -24,10 +24,11 @@ Results equal the packed engine's (and the reference's) up to summation order; `
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Tuple
+from typing import Callable, Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from . import ops
 from .model import _cfg_of, head_weight, packed_hidden_states
@@ -35,8 +36,76 @@ from .tree_training_engine import sum_loss_terms
 from .trie import pop_block_starts
 
 
+class _GradSink:
+    """Parameter gradients of a walk, summed over its blocks in PERSISTENT fp32 buffers.
+
+    The reference's `autograd.backward` per popped block runs `AccumulateGrad` over every parameter in model dtype (tte:440): the
+    sum over the 64 blocks of a config-5 call is rounded to bf16 / f16 after every add, and the embedding's gradient is materialised
+    as a dense, mostly-zero [vocab, hidden] matrix per block.  Here every block's backward writes fresh gradients (`p.grad` is None
+    when it starts), `absorb()` adds them into fp32 buffers, the embedding rows go straight into the tied weight's buffer by
+    `index_add` on the rows the block touched (`embed()`), and `finish()` rounds ONCE into `param.grad` (added to whatever gradient
+    the caller had accumulated before the call, as `backward()` must).  When the fp32 buffers do not fit `budget_bytes` the sink is
+    inactive and the blocks accumulate in model dtype as before."""
+
+    def __init__(self, model, budget_bytes: Optional[int]):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        need = 4 * sum(p.numel() for p in self.params)
+        self.active = bool(self.params) and (budget_bytes is None or need <= budget_bytes)
+        self.embed_weight = model.model.embed_tokens.weight
+        if not self.active:
+            return
+        self.orig = [p.grad for p in self.params]
+        self.bufs = [torch.zeros(p.shape, dtype=torch.float32, device=p.device) for p in self.params]
+        self._buf_of = {id(p): b for p, b in zip(self.params, self.bufs)}
+        for p in self.params:
+            p.grad = None
+
+    def embed(self, tokens: torch.Tensor) -> torch.Tensor:
+        w = self.embed_weight
+        if not (self.active and torch.is_grad_enabled() and w.requires_grad):
+            return F.embedding(tokens, w)
+        return _EmbedRows.apply(tokens, w, self._buf_of[id(w)])
+
+    def absorb(self) -> None:
+        if not self.active:
+            return
+        for p, b in zip(self.params, self.bufs):
+            if p.grad is not None:
+                b.add_(p.grad)
+                p.grad = None
+
+    def finish(self) -> None:
+        if not self.active:
+            return
+        for p, o, b in zip(self.params, self.orig, self.bufs):
+            if o is None:
+                p.grad = b.to(p.dtype)
+            else:
+                o.add_(b)                  # fp32 sum rounded once into the caller's gradient (a GradReducer view stays the same tensor)
+                p.grad = o
+        self.bufs = self.orig = None
+        self.active = False
+
+
+class _EmbedRows(torch.autograd.Function):
+    """Embedding lookup whose backward adds the rows' gradients into the sink's fp32 buffer of the (tied) embedding weight -
+    B rows touched instead of a dense [vocab, hidden] gradient per block (§6 profile of SURVEY: embedding-grad zero-fill per pop)."""
+
+    @staticmethod
+    def forward(ctx, tokens, weight, sink_buf):
+        ctx.save_for_backward(tokens)
+        ctx.sink = sink_buf
+        return F.embedding(tokens, weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        (tokens,) = ctx.saved_tensors
+        ctx.sink.index_add_(0, tokens, g.float())
+        return None, None, None
+
+
 class StackWalk:
-    def __init__(self, model, token_trie, device, dtype, block_rows: int, head_chunk: int = 2048, tp_group=None):
+    def __init__(self, model, token_trie, device, dtype, block_rows: int, head_chunk: int = 2048, tp_group=None, grad_budget_bytes: Optional[int] = None):
         self.model, self.trie, self.dev, self.dtype = model, token_trie, device, dtype
         self.block = max(int(block_rows), 1)
         self.head_chunk, self.tp_group = head_chunk, tp_group
@@ -60,6 +129,7 @@ class StackWalk:
         self.attachs: List[Tuple[dict, int]] = []
         self.cur = 0
         self.n_blocks = 0
+        self.sink = _GradSink(model, grad_budget_bytes)
 
     # ------------------------------------------------------------------------------------------
     def _attn_of_layer(self, start: int, with_grad: bool):
@@ -70,7 +140,8 @@ class StackWalk:
 
     def _hidden(self, s: int, e: int, with_grad: bool):
         pos = torch.arange(s, e, device=self.dev, dtype=torch.int32)
-        return packed_hidden_states(self.model, self.tokens[s:e].clone(), pos, None, False, 0, self._attn_of_layer(s, with_grad))
+        return packed_hidden_states(self.model, self.tokens[s:e].clone(), pos, None, False, 0, self._attn_of_layer(s, with_grad),
+                                    embed=self.sink.embed)
 
     def _head(self, h, s: int, e: int, want_forks: bool, last_label: bool = True):
         """(lp_next [B], lp_fork [F], ent [B], g_fork [F]) of rows s..e-1: lp_next[r-s] = log p(tokens[r+1] | row r) with the label of
@@ -82,16 +153,17 @@ class StackWalk:
             labels[-1] = -1                    # no chain child: -1 = no label (log-prob 0, no gradient)
         rows, toks, grads = [], [], []
         if want_forks:
-            for r in range(s, e):
-                for tok, g in self.pending.get(r, ()):
+            for r in sorted(k for k in self.pending if s <= k < e):        # the rows that HAVE picks (forks / block seams), not every row
+                for tok, g in self.pending[r]:
                     rows.append(r - s); toks.append(tok); grads.append(g)
         F_ = len(rows)
         if F_:
-            order = np.argsort(np.asarray(rows), kind="stable")
-            rows_np = np.asarray(rows, np.int64)[order]
-            fork_tok = torch.cat([toks[i] for i in order]); g_fork = torch.cat([grads[i] for i in order])
+            rows_np = np.asarray(rows, np.int64)                            # ascending by construction
+            fork_tok = torch.cat(toks); g_fork = torch.cat(grads)
             ptr = np.zeros(B + 1, np.int32); np.cumsum(np.bincount(rows_np, minlength=B), out=ptr[1:])
-            fork_ptr = torch.from_numpy(ptr).to(self.dev); fork_rows = torch.from_numpy(rows_np).to(self.dev)
+            from ._staging import upload                                    # asynchronous, out of page-locked staging: no host sync per block
+            (fork_ptr,) = upload([ptr], self.dev, np.int32)
+            (fork_rows,) = upload([rows_np], self.dev, np.int64)
             bounds = np.searchsorted(rows_np, np.arange(0, B + self.head_chunk, self.head_chunk)).tolist()
         else:
             fork_tok = self.tokens.new_zeros(0); g_fork = None; fork_ptr = None; fork_rows = self.tokens.new_zeros(0)
@@ -166,14 +238,15 @@ class StackWalk:
             if loss.requires_grad:                 # a callback may return constants for the sequences of a block
                 roots.append(loss); grads.append(None)
         torch.autograd.backward(roots, grads)
+        self.sink.absorb()
         if pre_lp is not None and s > 0:
             if pre_lp.grad is not None:
                 self.g_lp[1:s + 1] += pre_lp.grad
             if pre_ent.grad is not None:
                 self.g_ent[:s] += pre_ent.grad
         # hand the link of row s to row s-1, then clear what belonged to the popped rows (tte:471-485)
-        for r in range(s, e):
-            self.pending.pop(r, None)
+        for r in [k for k in self.pending if s <= k < e]:
+            del self.pending[r]
         if s > 0:
             self.pending.setdefault(s - 1, []).append((self.tokens[s:s + 1].clone(), self.g_lp[s:s + 1].clone()))
         self.g_lp[s:e].zero_(); self.g_ent[s:e].zero_()
@@ -214,4 +287,5 @@ class StackWalk:
             l = self.pop_to(0, loss_fn)
             if l is not None:
                 total = l if total is None else total + l
+        self.sink.finish()
         return total

@@ -185,12 +185,9 @@ class _PackedTrie:
 
 class TreeTrainingEngine:
     def __init__(self, model_config, device, dtype: torch.dtype, max_seq_len: int, forward_only: bool = False):
-        if torch.device(device).type == "cuda" and dtype not in (torch.bfloat16, torch.float16):
-            # the reference also runs fp32 models (run.py:122-132, through sdpa); the MFMA tree-attention kernels here are
-            # instantiated for the 16-bit dtypes only, so refuse up front with the reason instead of failing deep inside a layer
-            raise TypeError(f"TreeTrainingEngine on the MI355X HIP path supports dtype torch.bfloat16 / torch.float16, got {dtype}: "
-                            "there is no fp32 instantiation of the tree-attention kernels (use the reference on CPU, or the "
-                            "oracle in oracle/model_oracle.py, for fp32 gradient checks)")
+        if torch.device(device).type == "cuda" and dtype not in (torch.bfloat16, torch.float16, torch.float32):
+            raise TypeError(f"TreeTrainingEngine supports dtype torch.bfloat16 / torch.float16 (MFMA kernels) and torch.float32 (the reference's "
+                            f"--dtype fp32, run.py:122-132: plain-FMA attention kernels, a gradient-check path), got {dtype}")
         self.model = None
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:
@@ -213,6 +210,7 @@ class TreeTrainingEngine:
         self.partial_recompute = True                    # under recomputation, leading layers keep full activations while HBM allows
         self.tp_group = None                             # set to a process group to split the LM-head vocabulary across it
         self._attn_keep_planned = 0
+        self.stack_fp32_grads = True                     # block-wise walk: sum the blocks' parameter gradients in fp32 (False: model dtype, as the reference)
 
     # ------------------------------------------------------------------------------------------
     def _pack(self, token_trie) -> _PackedTrie:
@@ -283,7 +281,10 @@ class TreeTrainingEngine:
         from . import dp
         from .stack_engine import StackWalk
         dp.defer_active_reducers()          # parameters accumulate once per block here: reduce after the walk, not from the hooks
-        walk = StackWalk(model, token_trie, self.device, self.dtype, block_rows, self.head_chunk, self.tp_group)
+        # fp32 gradient buffers of the walk: a fifth of the budget at most (Qwen3-0.6B: 2.4 GB; 14B would need 59 GB and may not get it)
+        budget = self._budget()
+        walk = StackWalk(model, token_trie, self.device, self.dtype, block_rows, self.head_chunk, self.tp_group,
+                         grad_budget_bytes=0 if not self.stack_fp32_grads else (None if budget is None else budget // 5))
         total = walk.run(loss_fn)
         self.last_mode = f"stack[{block_rows}]x{walk.n_blocks}"
         self.cur_len = 0

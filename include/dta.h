@@ -34,7 +34,8 @@ extern "C" {
 
 #define DTA_BF16 0
 #define DTA_F16 1
-#define DTA_F32 2            /* log-prob / entropy kernels only (the reference calls them on logits.float(), vocab_parallel.py:16,24) */
+#define DTA_F32 2            /* fp32 models (reference --dtype fp32, run.py:122-132): plain-FMA attention kernels (a gradient-check path, not a
+                              * performance path), fp32 row kernels; and fp32 logits of the log-prob / entropy kernels (vocab_parallel.py:16,24) */
 
 #define DTA_QTILE 128        /* query rows per workgroup (fwd / dQ kernels)  */
 #define DTA_KTILE 128        /* key rows per workgroup (dK/dV kernel): 8 waves = 2 groups x (4 waves x 32 keys) sharing the keys */
@@ -84,7 +85,8 @@ int dta_preorder_meta(const int64_t* tokens, const int64_t* leaf_tok_off,
                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Tree attention (MFMA-bound).  head_dim must be 128; dtype DTA_BF16 or DTA_F16.
+ * Tree attention (MFMA-bound).  head_dim must be 128; dtype DTA_BF16 or DTA_F16 (MFMA kernels), or DTA_F32 (every buffer fp32;
+ * plain fp32 FMAs, one workgroup per 64 rows, split-Q work units ignored - the correctness path of fp32 models).
  *
  * q/out/dout/dq: [Tq, Hq, 128] with element strides (q_stride_t, 128); k/v/dk/dv: [Tk, Hkv, 128]
  * with (kv_stride_t, 128).  Query row i has packed index q_offset + i.  It attends key s iff

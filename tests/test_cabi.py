@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_every_declared_symbol_is_exported():
+    import torch  # noqa: F401  - torch's own libamdhip64 must be resident first (as _lib.lib() arranges): ONE HIP runtime per process
     from dynamictreeattn_amd.build import build_native
     lib = ctypes.CDLL(build_native())
     header = open(os.path.join(ROOT, "include", "dta.h")).read()

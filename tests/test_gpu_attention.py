@@ -131,7 +131,7 @@ def test_error_codes():
     P = lambda t: t.data_ptr()
     assert lib().dta_tree_attn_fwd(P(x), P(x), P(x), P(x), P(l), None, None, None, 4, 4, 0, 2, 2, 64, 128, 128, 128, 0.1, 0, None) == -2
     with pytest.raises(TypeError):
-        ops.tree_attention(x.float(), x.float(), x.float(), ops.stack_meta(0))
+        ops.tree_attention(x.double(), x.double(), x.double(), ops.stack_meta(0))
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.attn_fwd_raw(x.cpu(), x.cpu(), x.cpu(), ops.stack_meta(0), 1.0)
 

@@ -424,6 +424,28 @@ def test_blockwise_stack_engine_bf16_vs_reference_fp32(name, bs, eng_gold):
     assert float(np.median(list(ratios.values()))) <= REF_BF16_MEDIAN
 
 
+def test_blockwise_fp32_gradient_sums_are_closer_to_the_fp32_reference(monkeypatch):
+    """with many small blocks the model-dtype AccumulateGrad per block (the reference's tte:440) rounds the running sum
+    to bf16 after every block; the walk's fp32 sink rounds once.  Same trie, same kernels, block size 16: per-parameter |dg|/|g|
+    against the reference's fp32 gradients, sink on vs off - printed, and the fp32 sums must not be further away."""
+    out = {}
+    for name in ("d128_minitau", "d128_tree"):
+        g = torch.load(os.path.join(GOLD, "engine_tiny.pt"), weights_only=True)[name]
+        for fp32 in (True, False):
+            m, seqs = _setup(name, torch.bfloat16)
+            t = TokenTrie(seqs, _att(len(seqs))); t.backward_permute()
+            e = TreeTrainingEngine(m.config, DEV, torch.bfloat16, max(map(len, seqs)))
+            e.mode, e.stack_fp32_grads = "stack", fp32
+            monkeypatch.setattr(e, "_stack_block_rows", lambda *a: 16)      # really 16-row blocks (the engine would take what the HBM allows)
+            e.backward(m, t, mo.default_loss, 16)
+            r = [mo.grad_ratio(g["bwd_bs2048_grads"][n], p.grad.float().cpu()) for n, p in m.named_parameters()]
+            out[(name, fp32)] = (max(r), float(np.median(r)), float(np.mean(r)), e.last_mode)
+        a, b = out[(name, True)], out[(name, False)]
+        print(f"{name} block 16 ({a[3]}): fp32 sums worst {a[0]:.4e} median {a[1]:.4e} mean {a[2]:.4e} | model-dtype sums worst {b[0]:.4e} median {b[1]:.4e} mean {b[2]:.4e}")
+        assert a[2] <= b[2] * 1.02 and a[0] <= REF_BF16_BOUND
+    assert any(out[(n, True)][2] < 0.98 * out[(n, False)][2] for n in ("d128_minitau", "d128_tree"))
+
+
 QWEN3_4B_LAYER = dict(vocab_size=151936, hidden_size=2560, intermediate_size=9728, num_hidden_layers=2, num_attention_heads=32,
                       num_key_value_heads=8, head_dim=128, tie_word_embeddings=True, rms_norm_eps=1e-6, rope_theta=1e6)
 

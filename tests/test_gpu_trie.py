@@ -106,7 +106,7 @@ def test_preorder_meta_kernel_vs_host_mirror():
             assert torch.equal(pk.meta.ktile_qend.cpu(), ops.ktile_qend_from(pk.subtree_end).cpu())
 
 
-def test_engine_refuses_a_trie_on_another_device_and_fp32():
+def test_engine_refuses_a_trie_on_another_device_and_unsupported_dtypes():
     from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine, _PackedTrie
     from dynamictreeattn_amd import model as m
     t = TokenTrie(synth.as_tensors([[1, 2, 3], [1, 2, 4]]))
@@ -114,4 +114,5 @@ def test_engine_refuses_a_trie_on_another_device_and_fp32():
         _PackedTrie(t, torch.device("cuda", 1))                # no second GPU needed: the check is on the device ids
     cfg = m.make_config(synth.QWEN3_0P6B)
     with pytest.raises(TypeError, match="bfloat16 / torch.float16"):
-        TreeTrainingEngine(cfg, "cuda:0", torch.float32, 128)    # run.py:122-132 allows fp32; this HIP path states why it does not
+        TreeTrainingEngine(cfg, "cuda:0", torch.float64, 128)
+    TreeTrainingEngine(cfg, "cuda:0", torch.float32, 128)        # run.py:122-132 allows fp32: so does this engine (tests/test_gpu_fp32.py)
