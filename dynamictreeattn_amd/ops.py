@@ -365,6 +365,9 @@ def local_labels(t, vocab_offset, V):
     return torch.where((t >= vocab_offset) & (t < vocab_offset + V), t - vocab_offset, torch.full_like(t, -1))
 
 
+HEAD_WGRAD_FUSED_ACCUMULATE = False      # chunked head only: accumulate the weight gradient inside the GEMM (scripts/head_stage_probe.py measures both)
+
+
 class _HeadRows(torch.autograd.Function):
     """(lp_next [T], lp_fork [F], ent [T]) from hidden rows: lp_next[r] = log p(next_tok[r] | row r),
     lp_fork[f] = log p(fork_tok[f] | row of f), the forks given as a CSR over the rows (`fork_ptr` int32 [T+1]; the HIP
@@ -441,6 +444,8 @@ class _HeadRows(torch.autograd.Function):
                 pending.append(dist.all_reduce(dh[a:b], op=dist.ReduceOp.SUM, group=ctx.tp_group, async_op=True))
             if kept is not None:
                 dW = torch.mm(logits.t(), h)                 # one wgrad GEMM over all T rows (fp32 accumulate inside)
+            elif HEAD_WGRAD_FUSED_ACCUMULATE:
+                dW = torch.addmm(dW, logits.t(), h[a:b], out_dtype=torch.float32)      # hipBLASLt: 16-bit operands, fp32 C/D - no [V, hidden] temporary
             else:
                 dW += torch.mm(logits.t(), h[a:b])
         ctx.kept = None
