@@ -220,6 +220,7 @@ def main():
     model = build_model(cfg, dev, dtype)
     engine = TreeTrainingEngine(make_config(cfg), dev, dtype, max_seq_len=16384)     # run_all.py:86
     engine.mode = args.engine_mode
+    engine.stack_fp32_grads = os.environ.get("DTA_STACK_FP32_GRADS", "1") == "1"          # diagnostic A/B switch of the block-wise walk's fp32 gradient sums
     tp = args.vocab_parallel and world > 1
     if tp:
         engine.tp_group = dist.group.WORLD

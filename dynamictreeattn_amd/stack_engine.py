@@ -41,49 +41,60 @@ class _GradSink:
 
     The reference's `autograd.backward` per popped block runs `AccumulateGrad` over every parameter in model dtype (tte:440): the
     sum over the 64 blocks of a config-5 call is rounded to bf16 / f16 after every add, and the embedding's gradient is materialised
-    as a dense, mostly-zero [vocab, hidden] matrix per block.  Here every block's backward writes fresh gradients (`p.grad` is None
-    when it starts), `absorb()` adds them into fp32 buffers, the embedding rows go straight into the tied weight's buffer by
-    `index_add` on the rows the block touched (`embed()`), and `finish()` rounds ONCE into `param.grad` (added to whatever gradient
-    the caller had accumulated before the call, as `backward()` must).  When the fp32 buffers do not fit `budget_bytes` the sink is
-    inactive and the blocks accumulate in model dtype as before."""
+    as a dense, mostly-zero [vocab, hidden] matrix per block.  Here, for the duration of the walk, every `param.grad` is a view of ONE
+    flat model-dtype buffer that is zero when a block's backward starts; `absorb()` adds that buffer into ONE flat fp32 buffer and
+    clears it - two launches per block whatever the number of parameters (a per-parameter mixed-dtype add cost 5 ms per block in host
+    and launch time: 310 tensors) - the embedding rows go straight into the tied weight's fp32 slice by `index_add` on the rows the block
+    touched (`embed()`), and `finish()` rounds ONCE into `param.grad` (added to whatever gradient the caller had accumulated before
+    the call, as `backward()` must; a `dp.GradReducer` view stays the same tensor).  Inactive - the blocks then accumulate in model
+    dtype as the reference does - when the parameters are fp32 already, are not of one dtype on one device, or the buffers
+    (6 bytes per parameter) do not fit `budget_bytes`."""
 
     def __init__(self, model, budget_bytes: Optional[int]):
         self.params = [p for p in model.parameters() if p.requires_grad]
-        need = 4 * sum(p.numel() for p in self.params)
-        self.active = bool(self.params) and (budget_bytes is None or need <= budget_bytes)
         self.embed_weight = model.model.embed_tokens.weight
+        p0 = self.params[0] if self.params else None
+        n = sum(p.numel() for p in self.params)
+        self.active = (p0 is not None and p0.dtype in (torch.bfloat16, torch.float16)
+                       and all(p.dtype == p0.dtype and p.device == p0.device for p in self.params)
+                       and (budget_bytes is None or n * (4 + p0.element_size()) <= budget_bytes))
         if not self.active:
             return
         self.orig = [p.grad for p in self.params]
-        self.bufs = [torch.zeros(p.shape, dtype=torch.float32, device=p.device) for p in self.params]
-        self._buf_of = {id(p): b for p, b in zip(self.params, self.bufs)}
+        self.flat_lo = torch.zeros(n, dtype=p0.dtype, device=p0.device)
+        self.flat32 = torch.zeros(n, dtype=torch.float32, device=p0.device)
+        self._span, o = {}, 0
         for p in self.params:
-            p.grad = None
+            self._span[id(p)] = (o, o + p.numel())
+            p.grad = self.flat_lo[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def _f32(self, p) -> torch.Tensor:
+        a, b = self._span[id(p)]
+        return self.flat32[a:b].view_as(p)
 
     def embed(self, tokens: torch.Tensor) -> torch.Tensor:
         w = self.embed_weight
         if not (self.active and torch.is_grad_enabled() and w.requires_grad):
             return F.embedding(tokens, w)
-        return _EmbedRows.apply(tokens, w, self._buf_of[id(w)])
+        return _EmbedRows.apply(tokens, w, self._f32(w))
 
     def absorb(self) -> None:
-        if not self.active:
-            return
-        for p, b in zip(self.params, self.bufs):
-            if p.grad is not None:
-                b.add_(p.grad)
-                p.grad = None
+        if self.active:
+            self.flat32.add_(self.flat_lo)
+            self.flat_lo.zero_()
 
     def finish(self) -> None:
         if not self.active:
             return
-        for p, o, b in zip(self.params, self.orig, self.bufs):
+        for p, o in zip(self.params, self.orig):
+            g = self._f32(p)
             if o is None:
-                p.grad = b.to(p.dtype)
+                p.grad = g.to(p.dtype)
             else:
-                o.add_(b)                  # fp32 sum rounded once into the caller's gradient (a GradReducer view stays the same tensor)
+                o.add_(g)                  # fp32 sum rounded once into the caller's gradient
                 p.grad = o
-        self.bufs = self.orig = None
+        self.flat_lo = self.flat32 = self.orig = None
         self.active = False
 
 

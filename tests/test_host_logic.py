@@ -439,3 +439,28 @@ def test_loss_fn_may_return_a_plain_number_for_some_sequences(monkeypatch):
         if ref is None:
             ref = loss
         assert abs(loss - ref) < 1e-4 * abs(ref) and n_odd > 0
+
+
+def test_blockwise_fp32_gradient_sink_on_16bit_parameters():
+    """stack_engine._GradSink (bf16 parameters: flat model-dtype buffer absorbed into a flat fp32 buffer per block, one rounding at
+    the end): same gradients as the per-block model-dtype accumulation up to bf16 rounding, closer to the fp32 run, added to what
+    the caller already held in `param.grad`, and `param.grad` keeps the model dtype."""
+    from dynamictreeattn_amd.model import Qwen3TreeLM
+    case = cases.engine_cases()["d16_tree"]; cfg = cases.TINY_CFGS[case["cfg"]]
+    seqs = synth.as_tensors(synth.make_case(case["data"]))
+    w = mo.init_weights(cfg, seed=case["wseed"])
+
+    def run(dtype, sink, twice=False):
+        m = Qwen3TreeLM(cfg).load_named(w).to(dtype)
+        for _ in range(2 if twice else 1):
+            t = TokenTrie(seqs, _att(len(seqs)), device=CPU); t.backward_permute()
+            e = TreeTrainingEngine(m.config, "cpu", dtype, 4096); e.mode, e.stack_fp32_grads = "stack", sink
+            e.backward(m, t, mo.default_loss, 8)
+            assert e.last_mode.startswith("stack[8]")
+        assert all(p.grad.dtype == dtype for p in m.parameters())
+        return {n: p.grad.float() for n, p in m.named_parameters()}
+    ref = run(torch.float32, False)
+    on, off, on2 = run(torch.bfloat16, True), run(torch.bfloat16, False), run(torch.bfloat16, True, twice=True)
+    r_on = np.mean([mo.grad_ratio(ref[n], on[n]) for n in ref]); r_off = np.mean([mo.grad_ratio(ref[n], off[n]) for n in ref])
+    assert r_on <= r_off * 1.02 and r_on < 0.05, (r_on, r_off)
+    assert max(mo.grad_ratio(2 * on[n], on2[n]) for n in ref) < 2e-2          # a second call ADDS to the caller's gradient
