@@ -31,6 +31,46 @@
 #include <stdlib.h>
 #include "dta_common.h"
 
+// Diagnostic build switch (-DDTA_PRIO_HALF=1): static priority for the second-dispatched half of an 8-wave workgroup (waves 4-7 lose every
+// issue arbitration by age; MI355X_MICROARCH.md "Two waves per SIMD", item 4).  Measured in round 3: see DESIGN.md §9c.
+#if defined(DTA_PRIO_HALF) && DTA_PRIO_HALF
+#define DTA_PRIO_YOUNGER_HALF(W) if ((W) >= 4) __builtin_amdgcn_s_setprio(1);
+#else
+#define DTA_PRIO_YOUNGER_HALF(W)
+#endif
+
+// Diagnostic build switch (-DDTA_STAMP=1): in-kernel s_memtime stamps at the segment boundaries of the forward's tile loop, summed per
+// wave in scalar registers and written to a debug buffer of their own (cdna_hip_programming.md §7 "In-kernel stamps"); scripts/fwd_stamps.py
+// reads the SHARES.  No stamp executes in the product build.
+#if defined(DTA_STAMP) && DTA_STAMP
+__device__ unsigned long long* dta_stamp_buf = nullptr;
+extern "C" int dta_debug_set_stamp_buffer(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(dta_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -4; }
+#define DTA_STAMP_DECL unsigned long long st_prev_, st_sum_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long st_tiles_ = 0; \
+  __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev_) :: "memory"); __builtin_amdgcn_sched_barrier(0);
+#define DTA_STAMP_AT(K) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+  __builtin_amdgcn_sched_barrier(0); st_sum_[K] += t_ - st_prev_; st_prev_ = t_; }
+#define DTA_STAMP_TILE ++st_tiles_;
+#define DTA_STAMP_STORE if (dta_stamp_buf && lane == 0) { unsigned long long* o_ = dta_stamp_buf + ((size_t)blockIdx.x * 8 + wave) * 8; \
+  for (int k_ = 0; k_ < 6; ++k_) o_[k_] = st_sum_[k_]; o_[6] = st_tiles_; o_[7] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) /* HW_ID: wave / simd / cu ids */; }
+#else
+#define DTA_STAMP_DECL
+#define DTA_STAMP_AT(K)
+#define DTA_STAMP_TILE
+#define DTA_STAMP_STORE
+#endif
+
+// Waves of a forward / dQ workgroup that ISSUE the K/V tile DMA.  In an 8-wave workgroup the second-dispatched half (waves 4-7) loses every
+// issue arbitration on its SIMD and is the tile's critical path, while the first half waits a quarter of the tile at the barrier (stamps:
+// DESIGN.md §9c): -DDTA_DMA_OLDER_HALF=1 (diagnostic) lets waves 0-3 issue all 32 pieces (8 each) and the critical half none.  Measured:
+// the younger half's time moves from its DMA segment into its softmax / PV segments, the tile takes as long as before (zero-sum).
+#if defined(DTA_DMA_OLDER_HALF) && DTA_DMA_OLDER_HALF
+#define DTA_DMA_WAVES(HPB) 4
+#define DTA_DMA_GUARD(NW) if (wave < (NW))
+#else
+#define DTA_DMA_WAVES(HPB) (4 * (HPB))
+#define DTA_DMA_GUARD(NW)
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -235,7 +275,7 @@ __device__ __forceinline__ uint32_t dma_src_off(int row, int img_row, int lane, 
     voff_k[i_] = dma_src_off(row_, row_, lane, p.kv_st, sizeof(e));                                        \
     voff_v[i_] = dma_src_off(row_, row_, lane, p.v_st, sizeof(e)); }
 #define DTA_KV_DMA(BASE, K0, NW)                                                                           \
-  { char* base_ = (BASE); const int k0_ = (K0);                                                            \
+  DTA_DMA_GUARD(NW) { char* base_ = (BASE); const int k0_ = (K0);                                          \
     if (wave == 0) {                                                                                       \
       if (p.subtree_end) { int ki_ = k0_ + lane; ki_ = ki_ < p.Tk ? ki_ : p.Tk - 1;                        \
         dma_dword((uint32_t)ki_ * 4u, p.subtree_end, lds_addr(base_ + 2 * TILE_BYTES)); }                  \
@@ -260,11 +300,12 @@ __device__ __forceinline__ uint32_t dma_src_off(int row, int img_row, int lane, 
 template <int DT, int HPB>
 __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams p) {
   using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
-  constexpr int NW = 4 * HPB, BUF = 2 * TILE_BYTES + SE_BYTES;
+  constexpr int NW = DTA_DMA_WAVES(HPB), BUF = 2 * TILE_BYTES + SE_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[QK_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform values live in SGPRs
+  DTA_PRIO_YOUNGER_HALF(wave)
   const int hb = wave >> 2, rw = wave & 3;
   const int bid = blockIdx.x;
   const int hgroups = p.hgroups;
@@ -308,7 +349,9 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
 #define FWD_TILE(BUFI)                                                                                     \
   {                                                                                                        \
     int nk0_ = 0, nkend_ = 0; bool nmask_ = false;                                                         \
+    DTA_STAMP_AT(5) DTA_STAMP_TILE                                                                         \
     if (has_next) { nk0_ = it.k0; nkend_ = it.kend; nmask_ = it.masked(); DTA_KV_DMA(smem + (1 - (BUFI)) * BUF, it.k0, NW) } \
+    DTA_STAMP_AT(0)                                                                                        \
     const char* Ks = smem + (BUFI) * BUF; const char* Vs = Ks + TILE_BYTES;                                \
     const int* se_s = reinterpret_cast<const int*>(Ks + 2 * TILE_BYTES);                                   \
     f32x16 X[2];                                                                                           \
@@ -317,6 +360,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
       _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                        \
         X[kb] = T::mma(*reinterpret_cast<const v8*>(Ks + 8192 * kb + offs.row[s]), qf[s], X[kb]); \
     }                                                                                                      \
+    DTA_STAMP_AT(1)                                                                                        \
     if (cmask) {                                                                                           \
       const int qlim = qidx < ckend ? qidx : ckend - 1;      /* keys at or beyond the run end never count */ \
       _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                     \
@@ -343,22 +387,27 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
       _Pragma("unroll") for (int db = 0; db < 4; ++db)                                                     \
         _Pragma("unroll") for (int g = 0; g < 16; ++g) O[db][g] *= alpha;                                  \
     }                                                                                                      \
+    DTA_STAMP_AT(2)                                                                                        \
     _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                       \
       _Pragma("unroll") for (int g = 0; g < 16; ++g) { const float pv = fast_exp2(__builtin_fmaf(X[kb][g], c, -m)); lsum += pv; X[kb][g] = pv; } \
     _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                     \
       const v8 pb = pack_half<DT>(X[s4 >> 1], s4 & 1);                                                     \
       _Pragma("unroll") for (int db = 0; db < 4; ++db) O[db] = T::mma(tr_frag_o<v8>(Vs + 4096 * s4, offs, db), pb, O[db]); \
     }                                                                                                      \
+    DTA_STAMP_AT(3)                                                                                        \
     DMA_WAIT(); __syncthreads();               /* the next tile has landed in every wave's view */          \
+    DTA_STAMP_AT(4)                                                                                        \
     if (!has_next) break;                                                                                  \
     ck0 = nk0_; ckend = nkend_; cmask = nmask_;                                                            \
     has_next = it.advance();                                                                               \
   }
+  DTA_STAMP_DECL
   while (true) {
     FWD_TILE(0)
     FWD_TILE(1)
   }
 #undef FWD_TILE
+  DTA_STAMP_STORE
 
   lsum += __shfl_xor(lsum, 32);
   const float inv = 1.f / lsum;
@@ -387,6 +436,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_bwd_dq_kernel(AttnPara
 
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform values live in SGPRs
+  DTA_PRIO_YOUNGER_HALF(wave)
   const int hb = wave >> 2, rw = wave & 3;
   const int bid = blockIdx.x;
   const int hgroups = p.hgroups;
@@ -424,7 +474,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_bwd_dq_kernel(AttnPara
 
   const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
   const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.v_sh;
-  constexpr int NW = 4 * HPB, BUF = 2 * TILE_BYTES + SE_BYTES;
+  constexpr int NW = DTA_DMA_WAVES(HPB), BUF = 2 * TILE_BYTES + SE_BYTES;
   DTA_KV_OFFSETS(NW)                      // K/V tiles by LDS-DMA as in the forward (no staging registers, no ds_write)
 
   f32x16 DQ[4];
@@ -529,6 +579,7 @@ __global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p
   __shared__ __attribute__((aligned(16))) char smem_all[KV2_LDS];
   const int tid8 = threadIdx.x, tid = tid8 & 255, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid8 >> 6);       // 0..7
+  DTA_PRIO_YOUNGER_HALF(wave8)
   const int grp = wave8 >> 2, wave = wave8 & 3;
   char* kvs = smem_all + wave * 16384;                               // this key slot's K fragments (+8192: V)
   char* smem = smem_all + KV2_FRAGS;                                 // the Q/dO buffers
