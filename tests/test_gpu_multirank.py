@@ -51,7 +51,7 @@ def _model(dtype=torch.bfloat16):
     return Qwen3TreeLM.from_named(cfg, mo.init_weights(cfg, seed=1), DEV, dtype)
 
 
-def _dp_worker(rank, world, port, backend, outdir, one_leaf, overlap):
+def _dp_worker(rank, world, port, backend, outdir, one_leaf, overlap, stack=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     import torch.distributed as dist
     from dynamictreeattn_amd import dp
@@ -68,6 +68,9 @@ def _dp_worker(rank, world, port, backend, outdir, one_leaf, overlap):
     red = dp.GradReducer(model.parameters(), bucket_bytes=60000, overlap=overlap)
     assert len(red.buckets) > 3 and all(f.is_cuda for f in red.flats)
     eng = TreeTrainingEngine(model.config, DEV, torch.bfloat16, 1024)
+    if stack:                          # block-wise walk: parameters accumulate once per block into the walk's fp32 sink, the reducer's
+        eng.mode = "stack"             # hooks are deferred and everything goes out in finish()
+        eng._stack_block_rows = lambda *a: 256
     loss = None
     for it in range(2):                # the second step re-uses hooks and buffers (and must not see the first step's sums)
         if it == 0:
@@ -127,13 +130,14 @@ def test_engine_backward_under_live_reducer_one_rank_rccl(tmp_path):
         assert torch.equal(res["grads"][name], g), name
 
 
-@pytest.mark.parametrize("one_leaf,overlap", [(False, True), (True, True), (False, False)])
-def test_engine_backward_two_ranks_sharing_the_card_sum_to_full_batch(tmp_path, one_leaf, overlap):
+@pytest.mark.parametrize("one_leaf,overlap,stack", [(False, True, False), (True, True, False), (False, False, False), (False, True, True)])
+def test_engine_backward_two_ranks_sharing_the_card_sum_to_full_batch(tmp_path, one_leaf, overlap, stack):
     """Two gloo ranks on the one card, the batch split by `dp.my_bin` (LB_by_DFS_and_TM): after `finish()` BOTH ranks hold the sum
     of the per-bin gradients = the full-batch gradient, within the reference's recorded bf16 bound (sharing across bins is lost, so
     the arithmetic differs); `one_leaf`: rank 1's bin is empty."""
-    _run(_dp_worker, 2, (_free_port(), "gloo", str(tmp_path), one_leaf, overlap))
+    _run(_dp_worker, 2, (_free_port(), "gloo", str(tmp_path), one_leaf, overlap, stack))
     res = [torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=True) for r in range(2)]
+    assert all(r["mode"].startswith("stack[256]" if stack else "packed") for r in res if r["ids"])
     loss, grads, n = _full_batch_reference(one_leaf)
     assert sorted(res[0]["ids"] + res[1]["ids"]) == list(range(n))
     assert (res[1]["ids"] == []) == one_leaf
