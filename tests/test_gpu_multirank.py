@@ -150,6 +150,57 @@ def test_engine_backward_two_ranks_sharing_the_card_sum_to_full_batch(tmp_path, 
     assert float(np.median(list(ratios.values()))) <= 2.55e-2
 
 
+def _tp1_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    from dynamictreeattn_amd import ops
+    from dynamictreeattn_amd.token_trie import TokenTrie
+    from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    # (1) the sharded autograd Function of the public entry on RCCL: with one rank the shard is the whole vocabulary
+    g = torch.Generator().manual_seed(3)
+    logits = (torch.randn(40, 512, generator=g) * 3).to(DEV).requires_grad_(True)
+    labels = torch.randint(0, 512, (40,), generator=g).to(DEV)
+    go = [torch.randn(40, generator=g).to(DEV) for _ in range(2)]
+    lp, ent = ops.logprob_entropy(logits, labels, 0.7, True, dist.group.WORLD)          # per-shard statistics + ONE MAX + ONE SUM all-reduce
+    ((lp * go[0]).sum() + (ent * go[1]).sum()).backward()
+    res = {"lp": lp.detach().cpu(), "ent": ent.detach().cpu(), "g": logits.grad.cpu()}
+    logits.grad = None
+    lp0, ent0 = ops.logprob_entropy(logits, labels, 0.7, True, None)
+    ((lp0 * go[0]).sum() + (ent0 * go[1]).sum()).backward()
+    res.update(lp0=lp0.detach().cpu(), ent0=ent0.detach().cpu(), g0=logits.grad.cpu())
+    # (2) the engine with the LM-head vocabulary "split" over the 1-rank group (BASELINE config 4's code path: shard statistics,
+    #     combine, asynchronous all-reduce of dh under the weight-gradient GEMM) against the plain engine
+    out = {}
+    for tp in (False, True):
+        model = _model()
+        seqs = synth.as_tensors(synth.make_case(TAU2_BIN)); att = _att(len(seqs))
+        t = TokenTrie(seqs, att, device=DEV); t.backward_permute()
+        e = TreeTrainingEngine(model.config, DEV, torch.bfloat16, 1024)
+        if tp:
+            e.tp_group = dist.group.WORLD
+        loss = e.backward(model, t, mo.default_loss, 2048)
+        out[tp] = (loss, {n: p.grad.float().cpu() for n, p in model.named_parameters()})
+    res["engine"] = out
+    torch.save(res, os.path.join(outdir, "tp1.pt"))
+    dist.destroy_process_group()
+
+
+def test_vocab_parallel_code_path_on_rccl_with_one_rank(tmp_path):
+    """The collectives of BASELINE config 4 (MAX + packed SUM of the shard statistics, the dh all-reduce) executed by RCCL: a 1-rank
+    "nccl" group, where every reduce is the identity - the sharded Function must equal the unsharded kernels, and the engine with
+    `tp_group` set must equal the plain engine within bf16 rounding of the head stage."""
+    _run(_tp1_worker, 1, (_free_port(), str(tmp_path)))
+    r = torch.load(os.path.join(str(tmp_path), "tp1.pt"), weights_only=True)
+    assert torch.allclose(r["lp"], r["lp0"], atol=2e-6) and torch.allclose(r["ent"], r["ent0"], atol=5e-6)
+    assert torch.allclose(r["g"], r["g0"], atol=2e-6, rtol=1e-5)
+    (l0, g0), (l1, g1) = r["engine"][False], r["engine"][True]
+    assert abs(l0 - l1) <= 1e-3 * abs(l0)
+    assert max(mo.grad_ratio(g0[n], g1[n]) for n in g0) <= 2e-2
+
+
 def _vp_worker(rank, world, port, outdir):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     import torch.distributed as dist
