@@ -104,6 +104,9 @@ struct AttnParams {
   float scale; int32_t accumulate; int32_t ktile;
 };
 
+#ifndef DTA_FWD_FORM_DEFAULT
+#define DTA_FWD_FORM_DEFAULT 1
+#endif
 constexpr int TILE_BYTES = 64 * 256;           // 64 rows x 128 x 2 B
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -190,6 +193,13 @@ struct TileIter {
     *reinterpret_cast<u32x4*>((IMGB) + img_off(row_, ch_)) = REGB[i_];                                     \
   }
 
+// Deferred reference maximum of the forward (log2 domain): the running reference follows a tile's row maximum only when that exceeds it by
+// more than this, so P <= 2^THR (fp32 sums; bf16 P keeps its relative precision) and the rescale of O - taken on nine tiles in ten with
+// THR = 0, because ANY of a wave's rows triggers it - becomes rare.  -DDTA_FWD_THR=0 restores the exact-maximum form.
+#ifndef DTA_FWD_THR
+#define DTA_FWD_THR 4.0f
+#endif
+constexpr float FWD_THR = DTA_FWD_THR;
 constexpr int SE_BYTES = 256;                                       // 64 x int32 subtree_end of the staged keys
 constexpr int QK_LDS = 2 * (2 * TILE_BYTES + SE_BYTES);            // double-buffered {K image, V image, se}
 
@@ -292,6 +302,27 @@ __device__ __forceinline__ uint32_t dma_src_off(int row, int img_row, int lane, 
     _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); i_ += 2)                                            \
       dma_pair2(ok_[i_], ok_[i_ + 1], kb_, ov_[i_], ov_[i_ + 1], vb_, lds_addr(base_ + (wave * (16 / (NW)) + i_) * 1024)); }
 
+// The same tile DMA in two steps, so that a one-wave-per-SIMD kernel can issue the pieces BETWEEN its MFMAs instead of in one exposed burst
+// (8 pieces cost a wave ~900 cycles of issue): DTA_KV_DMA_PREP declares the bases / offsets (and sends the subtree_end row), DTA_KV_DMA_PAIR(i)
+// issues piece pair i (i = 0 .. 16/NW/2 - 1) of both images.
+#define DTA_KV_DMA_PREP(BASE, K0, NW, COND)                                                                    \
+  char* dbase_ = (BASE); const int dk0_ = (K0);                                                            \
+  if (wave == 0 && (COND)) {                                                                                      \
+    if (p.subtree_end) { int ki_ = dk0_ + lane; ki_ = ki_ < p.Tk ? ki_ : p.Tk - 1;                         \
+      dma_dword((uint32_t)ki_ * 4u, p.subtree_end, lds_addr(dbase_ + 2 * TILE_BYTES)); }                   \
+    else reinterpret_cast<int*>(dbase_ + 2 * TILE_BYTES)[lane] = 0x7fffffff; }                             \
+  const char* dkb_ = reinterpret_cast<const char*>(kbase) + (int64_t)dk0_ * p.kv_st * (int64_t)sizeof(e);  \
+  const char* dvb_ = reinterpret_cast<const char*>(vbase) + (int64_t)dk0_ * p.v_st * (int64_t)sizeof(e);   \
+  uint32_t dok_[16 / (NW)], dov_[16 / (NW)];                                                               \
+  _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) { dok_[i_] = voff_k[i_]; dov_[i_] = voff_v[i_]; } \
+  if (dk0_ + 64 > p.Tk) {                                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16 / (NW); ++i_) {                                             \
+      const int row_ = 4 * (wave * (16 / (NW)) + i_) + (lane >> 4);                                        \
+      const int rr_ = dk0_ + row_ < p.Tk ? row_ : p.Tk - 1 - dk0_;                                         \
+      dok_[i_] = dma_src_off(rr_, row_, lane, p.kv_st, sizeof(e)); dov_[i_] = dma_src_off(rr_, row_, lane, p.v_st, sizeof(e)); } }
+#define DTA_KV_DMA_PAIR(I, NW)                                                                             \
+  dma_pair2(dok_[2 * (I)], dok_[2 * (I) + 1], dkb_, dov_[2 * (I)], dov_[2 * (I) + 1], dvb_, lds_addr(dbase_ + (wave * (16 / (NW)) + 2 * (I)) * 1024));
+
 // =================================================================================================
 // forward.  HPB = query heads of one kv group handled by a workgroup (waves 4*hb .. 4*hb+3 own head hb);
 // they share the staged K/V tiles.  One barrier per 64-key tile, LDS double buffered, tile loop unrolled
@@ -380,7 +411,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
     _Pragma("unroll") for (int g = 0; g < 16; g += 2) mx = max3(mx, X[1][g], X[1][g + 1]);                 \
     mx = fmaxf(mx, __shfl_xor(mx, 32));                                                                    \
     const float mc = mx * c;                                                                               \
-    if (__any(mc > m)) {                       /* O is rescaled only when some row's maximum really grew */ \
+    if (__any(mc > m + FWD_THR)) {             /* O is rescaled only when some row's maximum grew by more than the deferral threshold */ \
       const float mnew = fmaxf(m, mc);                                                                     \
       const float alpha = fast_exp2(m - mnew);                                                             \
       m = mnew; lsum *= alpha;                                                                             \
@@ -423,6 +454,202 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
         *reinterpret_cast<v4*>(op + 32 * db + 8 * gq + 4 * h) = w;
       }
     if (h == 0) p.lse_w[(int64_t)hq * p.Tq + qrow] = m + __builtin_amdgcn_logf(lsum);   // v_log_f32 = log2
+  }
+}
+
+// =================================================================================================
+// forward, ONE wave per SIMD: a workgroup = 4 waves = 128 query rows, and every wave carries BOTH query heads of the kv group for its 32
+// rows (512 registers per lane: O 2 x 64, Q fragments 2 x 32, scores 2 x 32).
+//
+// Why: in-kernel stamps of the 8-wave form above show that vector instructions do not run in the shadow of the SIMD
+// PARTNER's MFMAs - a tile costs the SIMD its MFMA cycles PLUS both waves' vector-issue cycles - while they do run in the shadow of the
+// wave's OWN MFMAs.  Here the two heads are two independent instruction chains inside one wave: every K and V fragment read feeds two
+// MFMAs (half the LDS traffic per MFMA), and the exponentials / packs of both heads sit in the same basic block as the 32 PV MFMAs.
+// Same tile iteration, masks, staging (LDS-DMA, double buffer, one barrier per tile) and outputs as the 8-wave form.
+// =================================================================================================
+// Score MFMAs with a VGPR destination, from inline asm: with a 512-register budget hipcc puts the accumulators of EVERY builtin MFMA into
+// accumulation registers - right for O (128 registers nothing but the rare rescale touches), wrong for the scores, which the softmax
+// reads element by element (8 v_accvgpr moves per MFMA in the loop).  hipcc does not know these are MFMAs: the wait states between the
+// last one and the first vector read of its result (8-pass MFMA -> VALU: 11) are ours to provide - mfma_scores_done().
+template <int DT> struct MmaV;
+template <> struct MmaV<DTA_BF16> {
+  static __device__ __forceinline__ void first(f32x16& d, bf16x8 a, bf16x8 b) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b)); }
+  static __device__ __forceinline__ void acc(f32x16& d, bf16x8 a, bf16x8 b) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b)); }
+};
+template <> struct MmaV<DTA_F16> {
+  static __device__ __forceinline__ void first(f32x16& d, f16x8 a, f16x8 b) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b)); }
+  static __device__ __forceinline__ void acc(f32x16& d, f16x8 a, f16x8 b) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b)); }
+};
+__device__ __forceinline__ void mfma_scores_done(f32x16& a, f32x16& b, f32x16& c_, f32x16& d) {
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c_), "+v"(d));
+}
+constexpr float FWD3_THR = FWD_THR;          // the reference maximum follows a tile's row maximum only when that grew by more than this (log2 domain: P <= 16): the rescale of the 128 O accumulators (AGPR <-> VGPR moves) becomes rare
+__device__ __forceinline__ float half_max(float x) {      // max(x, value of the lane 32 away) by v_permlane32_swap (no LDS round trip)
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <int DT>
+__global__ __launch_bounds__(256, 1) void tree_attn_fwd3_kernel(AttnParams p) {
+  using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
+  constexpr int NW = 4, BUF = 2 * TILE_BYTES + SE_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[QK_LDS];
+
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bid = blockIdx.x;
+  const int hgroups = p.hgroups;
+  const int kvh = bid % p.Hkv; const int rest = bid / p.Hkv; const int hgb = rest % hgroups;
+  const int nqt = (p.Tq + DTA_QTILE - 1) / DTA_QTILE;
+  const int qt = nqt - 1 - rest / hgroups;
+  const int hq0 = kvh * p.group + p.head0 + hgb * 2;                 // this workgroup's two query heads: hq0, hq0 + 1
+  const int q0 = qt * DTA_QTILE;
+  const int qrow = q0 + wave * 32 + r;
+  const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
+  const int qidx = p.q_offset + qrow;
+
+  TileIter it; it.runs = p.runs; it.diag_first_q = p.q_offset + q0;
+  if (p.runs) { it.ri = p.run_ptr[qt]; it.re = p.run_ptr[qt + 1]; if (!it.load_run()) return; }
+  else { it.ri = 0; it.re = 1; it.k0 = 0; it.flag = 1; int last = p.q_offset + (q0 + DTA_QTILE < p.Tq ? q0 + DTA_QTILE : p.Tq); it.kend = last < p.Tk ? last : p.Tk; if (it.kend <= 0) return; }
+
+  v8 qf[2][8];
+#pragma unroll
+  for (int hd = 0; hd < 2; ++hd) {
+    const e* qp = reinterpret_cast<const e*>(p.q) + (int64_t)qrow_c * p.q_st + (int64_t)(hq0 + hd) * p.q_sh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { qf[hd][s] = *reinterpret_cast<const v8*>(qp + 16 * s + 8 * h); asm volatile("" : "+a"(qf[hd][s])); }   // Q fragments live in accumulation registers (pure MFMA operands)
+  }
+  const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
+  const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.v_sh;
+  const FragOffs offs = frag_offsets(lane);
+  DTA_KV_OFFSETS(NW)
+
+  f32x16 O[2][4];
+#pragma unroll
+  for (int hd = 0; hd < 2; ++hd)
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) O[hd][db][g] = 0.f;
+  float m[2] = {-1e30f, -1e30f}, lsum[2] = {0.f, 0.f};
+  const float c = p.scale * LOG2E;
+
+  int ck0 = it.k0, ckend = it.kend; bool cmask = it.masked();
+  DTA_KV_DMA(smem, it.k0, NW)
+  bool has_next = it.advance();
+  DMA_WAIT(); __syncthreads();
+
+  int cur = 0;
+  bool more = true;
+  do {          // ONE straight-line body with a single exit at the bottom and a run-time buffer toggle: with two unrolled bodies and exits from the
+                // middle hipcc carried the 128 O accumulators in VGPRs between them (128 v_accvgpr moves each way per tile)
+    int nk0_ = 0, nkend_ = 0; bool nmask_ = false;
+    if (has_next) { nk0_ = it.k0; nkend_ = it.kend; nmask_ = it.masked(); }
+    DTA_KV_DMA_PREP(smem + (cur ^ 1) * BUF, has_next ? it.k0 : 0, NW, has_next)
+    const char* Ks = smem + cur * BUF; const char* Vs = Ks + TILE_BYTES;
+    const int* se_s = reinterpret_cast<const int*>(Ks + 2 * TILE_BYTES);
+    f32x16 X[2][2];
+    { v8 kf[2][8];                           /* all 16 K fragments requested up front (64 registers): one LDS latency per tile, not one per MFMA pair */
+      #pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        #pragma unroll
+      for (int s = 0; s < 8; ++s) kf[kb][s] = *reinterpret_cast<const v8*>(Ks + 8192 * kb + offs.row[s]);
+      #pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        #pragma unroll
+      for (int s = 0; s < 8; ++s) {                    /* one K fragment, two MFMAs */
+          if (s == 0) { MmaV<DT>::first(X[0][kb], kf[kb][s], qf[0][s]); MmaV<DT>::first(X[1][kb], kf[kb][s], qf[1][s]); }
+          else { MmaV<DT>::acc(X[0][kb], kf[kb][s], qf[0][s]); MmaV<DT>::acc(X[1][kb], kf[kb][s], qf[1][s]); }
+          if (s == 3 && has_next) { if (kb == 0) { DTA_KV_DMA_PAIR(0, NW) } else { DTA_KV_DMA_PAIR(1, NW) } }      // the next tile's DMA pieces go out between the MFMAs
+        }
+    }
+    mfma_scores_done(X[0][0], X[0][1], X[1][0], X[1][1]);
+    if (cmask) {
+      const int qlim = qidx < ckend ? qidx : ckend - 1;
+      #pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        #pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+          const int kl = 32 * kb + 8 * gq + 4 * h;
+          const int4 se4 = *reinterpret_cast<const int4*>(se_s + kl);
+          const int sev[4] = {se4.x, se4.y, se4.z, se4.w};
+          #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+            const bool ok = (ck0 + kl + j <= qlim) && (qidx < sev[j]);
+            X[0][kb][4 * gq + j] = ok ? X[0][kb][4 * gq + j] : -INFINITY;
+            X[1][kb][4 * gq + j] = ok ? X[1][kb][4 * gq + j] : -INFINITY;
+          }
+        }
+    }
+    float mc[2];
+    #pragma unroll
+      for (int hd = 0; hd < 2; ++hd) {
+      float mx = max3(X[hd][0][0], X[hd][0][1], X[hd][0][2]);
+      #pragma unroll
+      for (int g = 3; g < 15; g += 2) mx = max3(mx, X[hd][0][g], X[hd][0][g + 1]);
+      mx = fmaxf(mx, X[hd][0][15]);
+      #pragma unroll
+      for (int g = 0; g < 16; g += 2) mx = max3(mx, X[hd][1][g], X[hd][1][g + 1]);
+      mc[hd] = half_max(mx) * c;
+    }
+    if (__builtin_expect(__any((mc[0] > m[0] + FWD3_THR) || (mc[1] > m[1] + FWD3_THR)), 0)) {   /* COLD side path, both heads at once: the O <-> VGPR moves belong in here */
+      #pragma unroll
+      for (int hd = 0; hd < 2; ++hd) {
+        const float mnew = fmaxf(m[hd], mc[hd]);
+        const float alpha = fast_exp2(m[hd] - mnew);
+        m[hd] = mnew; lsum[hd] *= alpha;
+        #pragma unroll
+      for (int db = 0; db < 4; ++db)
+          #pragma unroll
+      for (int g = 0; g < 16; ++g) O[hd][db][g] *= alpha;
+      }
+    }
+    /* exponentials / packs of both heads and the 32 PV MFMAs: one basic block, every V fragment read feeds two MFMAs */
+    #pragma unroll
+      for (int hd = 0; hd < 2; ++hd)
+      #pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        #pragma unroll
+      for (int g = 0; g < 16; ++g) { const float pv = fast_exp2(__builtin_fmaf(X[hd][kb][g], c, -m[hd])); lsum[hd] += pv; X[hd][kb][g] = pv; }
+    #pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+      const v8 pb0 = pack_half<DT>(X[0][s4 >> 1], s4 & 1);
+      const v8 pb1 = pack_half<DT>(X[1][s4 >> 1], s4 & 1);
+      #pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const v8 vf = tr_frag_o<v8>(Vs + 4096 * s4, offs, db);
+        O[0][db] = T::mma(vf, pb0, O[0][db]);
+        O[1][db] = T::mma(vf, pb1, O[1][db]);
+      }
+    }
+    /* the loop-carried home of O is the accumulation file (hipcc otherwise carries it in VGPRs and moves 128 registers each way per tile) */
+    #pragma unroll
+      for (int db = 0; db < 4; ++db) { asm volatile("" : "+a"(O[0][db])); asm volatile("" : "+a"(O[1][db])); }
+    DMA_WAIT(); __syncthreads();
+    more = has_next;
+    ck0 = nk0_; ckend = nkend_; cmask = nmask_; cur ^= 1;
+    if (more) has_next = it.advance();
+  } while (more);
+
+#pragma unroll
+  for (int hd = 0; hd < 2; ++hd) {
+    float l = lsum[hd];
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+    if (qrow < p.Tq) {
+      e* op = reinterpret_cast<e*>(p.out) + (int64_t)qrow * p.o_st + (int64_t)(hq0 + hd) * p.o_sh;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          v4 w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = (e)(O[hd][db][4 * gq + j] * inv);
+          *reinterpret_cast<v4*>(op + 32 * db + 8 * gq + 4 * h) = w;
+        }
+      if (h == 0) p.lse_w[(int64_t)(hq0 + hd) * p.Tq + qrow] = m[hd] + __builtin_amdgcn_logf(l);
+    }
   }
 }
 
@@ -889,8 +1116,14 @@ extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v,
   if (npair > 0) {
     p.hgroups = npair; p.head0 = 0;
     dim3 grid(nqt * Hkv * npair), block(512);
-    if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_BF16, 2>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_F16, 2>), grid, block, 0, st, p);
+    static const int form = [] { const char* e_ = getenv("DTA_FWD_FORM"); return e_ ? atoi(e_) : DTA_FWD_FORM_DEFAULT; }();   // 1: 8 waves, one head each; 3: 4 waves, two heads each, one wave per SIMD (A/B switch)
+    if (form == 3) {
+      if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd3_kernel<DTA_BF16>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((tree_attn_fwd3_kernel<DTA_F16>), grid, dim3(256), 0, st, p);
+    } else {
+      if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_BF16, 2>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_F16, 2>), grid, block, 0, st, p);
+    }
   }
   if (p.group % 2) {
     p.hgroups = 1; p.head0 = p.group - 1;
