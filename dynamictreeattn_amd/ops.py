@@ -783,6 +783,33 @@ def clear_stack_rows_cache() -> None:
     _StackRows._cache.clear(); _StackRows._cached_bytes = 0
 
 
+WGRAD_SPLIT_K = 4          # slices of the packed rows in the weight-gradient GEMM of a small projection (0 / 1: never split)
+
+
+def _wgrad(x: torch.Tensor, dy: torch.Tensor, transposed: bool) -> torch.Tensor:
+    """dW[out, in] = dyᵀ[out, T] · x[T, in] - few output tiles, long K.  Qwen3-0.6B's q/k/v, o and down projections give 32-64 tiles of
+    256x256 for 256 CUs with K = T ≈ 28 k: hipBLASLt runs them at 580-720 TFLOP/s.  A manual split-K fills the chip: the T rows are cut
+    into `WGRAD_SPLIT_K` equal slices (multiples of 256 rows), ONE batched GEMM forms the slices' products with fp32 outputs, and they
+    are summed in fp32 and rounded once (closer to the exact product than the single bf16-output GEMM) - 0.344 -> 0.260 ms (q/k/v),
+    0.203 -> 0.147 (o), 0.248 -> 0.201 (down) at T = 28 160 (scripts/gemm_splitk_probe.py; gate/up with 96 tiles does not gain and
+    larger geometries have enough tiles).  `transposed`: form xᵀ·dy and return its transpose view (_Linear's layout choice)."""
+    T = x.shape[0]
+    a, b = (x, dy) if transposed else (dy, x)                    # result = aᵀ · b
+    S = WGRAD_SPLIT_K
+    tiles = -(-a.shape[1] // 256) * -(-b.shape[1] // 256)
+    per = (T // S) // 256 * 256 if S > 1 else 0
+    if S <= 1 or tiles > 64 or per < 2048 or not x.is_cuda or x.dtype == torch.float32:
+        out = a.t() @ b
+    else:
+        body = per * S
+        part = torch.bmm(a[:body].view(S, per, a.shape[1]).transpose(1, 2), b[:body].view(S, per, b.shape[1]), out_dtype=torch.float32)
+        acc = part.sum(0)
+        if body < T:
+            acc += torch.mm(a[body:].t(), b[body:], out_dtype=torch.float32)
+        out = acc.to(x.dtype)
+    return out.t() if transposed else out
+
+
 class _Linear(torch.autograd.Function):
     """y = x Wᵀ (+ b) over packed rows with the weight-gradient GEMM issued in the layout hipBLASLt runs faster on
     gfx950: for a projection that narrows by 2x or more (Qwen3-0.6B o_proj 2048->1024, down_proj 3072->1024) `xᵀ·dy`
@@ -801,7 +828,7 @@ class _Linear(torch.autograd.Function):
         dx = dy @ w if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = (x.t() @ dy).t() if w.shape[1] >= 2 * w.shape[0] else dy.t() @ x
+            dw = _wgrad(x, dy, w.shape[1] >= 2 * w.shape[0])
         db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
