@@ -294,6 +294,58 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const void* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 2-D transpose through a 64x64 LDS tile of 32-bit words, 16-byte global accesses on both sides.
+//   4-byte elements: word[c][r] = in[r][c].
+//   2-byte elements: a lane loads the 8-element chunks of TWO consecutive rows and packs (in[r][c], in[r+1][c]) into one word, so the tile
+//   is transposed at word granularity ([c][r/2], 32 words per output row) and the write phase reads 4 consecutive words = 8 output
+//   elements with one ds_read_b128.  Row pitch = odd number of words (+1 word of padding x alignment): the column-wise writes of the
+//   load phase spread over the banks.
+template <int ESZ>
+__global__ __launch_bounds__(256) void transpose_kernel(const char* __restrict__ in, char* __restrict__ out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out) {
+  constexpr int TS = 64;
+  constexpr int WPR = ESZ == 2 ? TS / 2 : TS;         // words per transposed tile row
+  constexpr int PITCH = WPR + 4;                      // words; +4 keeps 16-byte alignment of the rows for the b128 reads (2-way conflicts at worst)
+  __shared__ __attribute__((aligned(16))) uint32_t tile[TS * PITCH];
+  const int64_t r0 = (int64_t)blockIdx.y * TS, c0 = (int64_t)blockIdx.x * TS;
+  const int tid = threadIdx.x;
+  if (ESZ == 2) {
+    // load: 32 row pairs x 8 chunks of 8 columns = 256 items, one per thread
+    const int rp = tid >> 3, ch = tid & 7, r = 2 * rp, c = 8 * ch;
+    uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+    if (c0 + c < cols) {
+      if (r0 + r < rows) a = *reinterpret_cast<const uint4*>(in + ((r0 + r) * ld_in + c0 + c) * 2);
+      if (r0 + r + 1 < rows) b = *reinterpret_cast<const uint4*>(in + ((r0 + r + 1) * ld_in + c0 + c) * 2);
+    }
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                     // columns c+2j (low halves) and c+2j+1 (high halves)
+      tile[(c + 2 * j) * PITCH + rp] = (aw[j] & 0xffffu) | (bw[j] << 16);
+      tile[(c + 2 * j + 1) * PITCH + rp] = (aw[j] >> 16) | (bw[j] & 0xffff0000u);
+    }
+    __syncthreads();
+    // store: 64 output rows (input columns) x 8 chunks of 8 output elements (4 words)
+    for (int i = tid; i < TS * 8; i += 256) {
+      const int oc = i >> 3, k = i & 7;               // output row oc (= input column), output elements 8k .. 8k+7 (= input rows)
+      if (c0 + oc < cols && r0 + 8 * k < rows)
+        *reinterpret_cast<uint4*>(out + ((c0 + oc) * ld_out + r0 + 8 * k) * 2) = *reinterpret_cast<const uint4*>(&tile[oc * PITCH + 4 * k]);
+    }
+  } else {
+    for (int i = tid; i < TS * 16; i += 256) {        // 64 rows x 16 chunks of 4 columns
+      const int r = i >> 4, c = 4 * (i & 15);
+      uint4 a = make_uint4(0, 0, 0, 0);
+      if (r0 + r < rows && c0 + c < cols) a = *reinterpret_cast<const uint4*>(in + ((r0 + r) * ld_in + c0 + c) * 4);
+      tile[(c + 0) * PITCH + r] = a.x; tile[(c + 1) * PITCH + r] = a.y; tile[(c + 2) * PITCH + r] = a.z; tile[(c + 3) * PITCH + r] = a.w;
+    }
+    __syncthreads();
+    for (int i = tid; i < TS * 16; i += 256) {
+      const int oc = i >> 4, k = i & 15;
+      if (c0 + oc < cols && r0 + 4 * k < rows)
+        *reinterpret_cast<uint4*>(out + ((c0 + oc) * ld_out + r0 + 4 * k) * 4) = *reinterpret_cast<const uint4*>(&tile[oc * PITCH + 4 * k]);
+    }
+  }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int row_blocks(int64_t rows, int per_block, int cap) { int64_t b = (rows + per_block - 1) / per_block; return (int)(b < cap ? (b > 0 ? b : 1) : cap); }
 
@@ -373,4 +425,20 @@ extern "C" int dta_swiglu_bwd(const void* gate, const void* up, const void* dy, 
   if (!al16(gate) || !al16(up) || !al16(dy) || !al16(dgate) || !al16(dup)) return DTA_EALIGN;
   const int64_t n8 = rows * (cols / 8);
   DTA_DISPATCH(swiglu_bwd_kernel, row_blocks(n8, 256, 4096), gate, up, dy, dgate, dup, n8, cols / 8, ld, ld_grad);
+}
+
+
+extern "C" int dta_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, int32_t elem_size, void* stream) {
+  if (!in || !out || rows <= 0 || cols <= 0 || ld_in < cols || ld_out < rows) return DTA_EINVAL;
+  if (elem_size != 2 && elem_size != 4) return DTA_EUNSUPPORTED;
+  const int V = 16 / elem_size;
+  if (rows % V || cols % V || ld_in % V || ld_out % V) return DTA_EUNSUPPORTED;
+  if (!al16(in) || !al16(out)) return DTA_EALIGN;
+  hipStream_t st_ = static_cast<hipStream_t>(stream);
+  DTA_REFUSE_IF_PRIOR_ERROR();
+  const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64)), block(256);
+  if (grid.y > 65535) return DTA_EUNSUPPORTED;
+  if (elem_size == 2) hipLaunchKernelGGL(transpose_kernel<2>, grid, block, 0, st_, (const char*)in, (char*)out, rows, cols, ld_in, ld_out);
+  else hipLaunchKernelGGL(transpose_kernel<4>, grid, block, 0, st_, (const char*)in, (char*)out, rows, cols, ld_in, ld_out);
+  return DTA_LAUNCH_STATUS();
 }

@@ -208,6 +208,12 @@ int dta_swiglu_fwd(const void* gate, const void* up, void* y, int64_t rows, int3
 int dta_swiglu_bwd(const void* gate, const void* up, const void* dy, void* dgate, void* dup,
                    int64_t rows, int32_t cols, int64_t ld, int64_t ld_grad, int32_t dtype, void* stream);
 
+/* out[c][r] = in[r][c]: `rows` x `cols` elements of `elem_size` bytes (2: bf16 / f16, 4: f32), `ld_in` / `ld_out` elements between rows (both
+ * multiples of 8 elements, pointers 16-byte aligned).  HBM-bound (one read + one write).  Used for transposed copies of the projection and
+ * LM-head weights, made once per weight version: the input-gradient GEMMs dx = dy . W of the model calls (tree_training_engine.py:440,
+ * torch.autograd.backward) run 12-25 % faster with the contraction index contiguous in both operands. */
+int dta_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, int32_t elem_size, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,3 +99,26 @@ def test_pending_hip_error_is_reported_not_swallowed():
     y = ops.swiglu(g, g)                                          # the report cleared it
     torch.cuda.synchronize()
     assert torch.isfinite(y.float()).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("R,C", [(64, 64), (1024, 4096), (3072, 1024), (200, 72), (8, 8), (151936, 1024)])
+def test_transpose_kernel_bit_exact(R, C, dtype):
+    """dta_transpose: out[c][r] = in[r][c], ragged tiles included, the LM-head shape included."""
+    g = torch.Generator().manual_seed(R * 31 + C)
+    x = torch.randn(R, C, generator=g).to(dtype).to(DEV)
+    y = ops.transpose_2d(x)
+    assert y.shape == (C, R) and y.is_contiguous() and torch.equal(y, x.t().contiguous())
+
+
+def test_transposed_weight_cache_follows_the_weight_version():
+    w = torch.nn.Parameter(torch.randn(512, 256, device=DEV).bfloat16())
+    a = ops._TransposedWeights.get(w); b = ops._TransposedWeights.get(w)
+    assert a.data_ptr() == b.data_ptr() and torch.equal(a, w.t())
+    with torch.no_grad():
+        w.add_(1.0)                                  # an optimizer step: the version counter moves, the copy is re-made
+    c = ops._TransposedWeights.get(w)
+    assert torch.equal(c, w.t())
+    x = torch.randn(5000, 512, device=DEV).bfloat16()
+    assert torch.allclose(ops._dgrad(x, w).float(), (x @ w).float(), rtol=2e-2, atol=2e-1)
+    ops.clear_weight_caches()
