@@ -253,7 +253,6 @@ def main():
     def step(mine, acc=None):
         """One pass of the hot path over this rank's sequences (possibly none: an empty bin still takes part in the reduce)."""
         zero()
-        ops.clear_weight_caches()        # no optimizer here: every step re-makes its per-weight-version copies, as a training step does
         t_begin = time.time()
         trie = TokenTrie(mine, [dict(attach) for _ in mine], device=dev)
         if mine:

@@ -23,17 +23,19 @@ def _one(model, ids: torch.Tensor, want_entropy: bool, checkpoint_layers: bool):
 @torch.no_grad()
 def forward(model, token_seqs: List[torch.LongTensor], use_tqdm: bool = False) -> List[torch.Tensor]:
     out = []
-    for ids in token_seqs:
-        lp, _ = _one(model, ids.to(model.device), False, False)
-        out.append(lp[1:])
+    with ops.weight_cache():
+        for ids in token_seqs:
+            lp, _ = _one(model, ids.to(model.device), False, False)
+            out.append(lp[1:])
     return out
 
 
 def backward(model, token_seqs: List[torch.LongTensor], attachs, loss_fn, act_ckpt: bool = False, use_tqdm: bool = False) -> float:
     total = 0.0
-    for ids, att in zip(token_seqs, attachs):
-        lp, ent = _one(model, ids.to(model.device), True, act_ckpt)
-        loss = loss_fn(lp[1:], ent, att)
-        loss.backward()
-        total += loss.item()
+    with ops.weight_cache():
+        for ids, att in zip(token_seqs, attachs):
+            lp, ent = _one(model, ids.to(model.device), True, act_ckpt)
+            loss = loss_fn(lp[1:], ent, att)
+            loss.backward()
+            total += loss.item()
     return total

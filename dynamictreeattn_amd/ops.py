@@ -733,12 +733,31 @@ def swiglu_fused(gu: torch.Tensor) -> torch.Tensor:
     return _SwiGLU.apply(gu, None, None)
 
 
+class weight_cache:
+    """Scope in which per-weight copies (stacked projection rows, transposed weights) are shared: ONE engine call (`forward`, `backward`,
+    a dense pass).  Inside it every layer call, the recomputation pass and every block of the block-wise walk reuse one copy per weight;
+    when the outermost scope ends the copies are dropped - the optimizer step that follows changes the weights anyway, and nothing is keyed
+    across calls on identifiers a later tensor could recycle (object ids, storage addresses, version counters: a cache that outlived the
+    call once served another model's layer to a new one in the test suite).  Outside any scope nothing is cached."""
+    depth = 0
+
+    def __enter__(self):
+        weight_cache.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        weight_cache.depth -= 1
+        if weight_cache.depth == 0:
+            clear_weight_caches()
+        return False
+
+
 class _StackRows(torch.autograd.Function):
     """Concatenate weight matrices along dim 0 into one GEMM operand.  Backward hands each input its row
     slice of the fused gradient as a VIEW (no copy); forward is len(ws) plain copies (torch.cat's batched
-    copy kernel took 170 us for two 6 MB inputs on gfx950) - and none at all when the same weights, unchanged
-    (same storage, same in-place version counter), were stacked before: every layer call of a step, the recomputation
-    pass and every block of the block-wise walk then share ONE fused copy until the optimizer updates the weights."""
+    copy kernel took 170 us for two 6 MB inputs on gfx950) - and none at all when the same weights were stacked before
+    INSIDE THE SAME `weight_cache` SCOPE (one engine call): every layer call of a step, the recomputation pass and every block
+    of the block-wise walk share ONE fused copy."""
 
     CACHE_BYTES = 8 << 30            # fused copies kept at most (Qwen3-0.6B: 0.59 GB, Qwen3-4B: 4.7 GB); beyond it, copy per call
     _cache: dict = {}
@@ -746,24 +765,19 @@ class _StackRows(torch.autograd.Function):
 
     @staticmethod
     def _fused(ws):
-        key = tuple(id(w) for w in ws)
-        sig = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws)
-        hit = _StackRows._cache.get(key)
-        if hit is not None and hit[0] == sig:
-            return hit[1]
         rows = [w.shape[0] for w in ws]
-        reuse = hit is not None and hit[1].dtype == ws[0].dtype and hit[1].device == ws[0].device and hit[1].shape[0] == sum(rows)
-        out = hit[1] if reuse else torch.empty((sum(rows),) + tuple(ws[0].shape[1:]), dtype=ws[0].dtype, device=ws[0].device)
+        key = tuple((id(w), w.data_ptr(), w._version) for w in ws)
+        if weight_cache.depth > 0:
+            hit = _StackRows._cache.get(key)
+            if hit is not None:
+                return hit
+        out = torch.empty((sum(rows),) + tuple(ws[0].shape[1:]), dtype=ws[0].dtype, device=ws[0].device)
         o = 0
         for w, r in zip(ws, rows):
             out[o:o + r].copy_(w); o += r
         nbytes = out.numel() * out.element_size()
-        if reuse:
-            _StackRows._cache[key] = (sig, out)
-        elif _StackRows._cached_bytes + nbytes <= _StackRows.CACHE_BYTES:
-            if hit is not None:
-                _StackRows._cached_bytes -= hit[1].numel() * hit[1].element_size()
-            _StackRows._cache[key] = (sig, out); _StackRows._cached_bytes += nbytes
+        if weight_cache.depth > 0 and _StackRows._cached_bytes + nbytes <= _StackRows.CACHE_BYTES:
+            _StackRows._cache[key] = out; _StackRows._cached_bytes += nbytes
         return out
 
     @staticmethod
@@ -799,33 +813,29 @@ def transpose_2d(w: torch.Tensor) -> torch.Tensor:
 
 
 class _TransposedWeights:
-    """Transposed copies of weight matrices, one per weight VERSION (storage pointer + in-place version counter): made once per optimizer
-    step, shared by every use of the weight in that step (recomputation passes, blocks of the block-wise walk).  Same 8 GB bound as
-    the stacked-rows cache; beyond it the copy is made per call."""
+    """Transposed copies of weight matrices, one per weight inside a `weight_cache` scope (one engine call): shared by every use of the weight
+    in that call (recomputation passes, blocks of the block-wise walk).  Same 8 GB bound as the stacked-rows cache; beyond it, and outside a
+    scope, the copy is made per use."""
     cache: dict = {}
     nbytes = 0
 
     @staticmethod
     def get(w: torch.Tensor) -> torch.Tensor:
-        key = (w.data_ptr(), tuple(w.shape), w.dtype)
+        if weight_cache.depth == 0:
+            return transpose_2d(w)
+        key = (w.data_ptr(), tuple(w.shape), w.dtype, w._version)
         hit = _TransposedWeights.cache.get(key)
-        if hit is not None and hit[0] == w._version:
-            return hit[1]
+        if hit is not None:
+            return hit
         wt = transpose_2d(w)
         n = wt.numel() * wt.element_size()
-        if hit is not None:
-            _TransposedWeights.nbytes -= hit[1].numel() * hit[1].element_size()
         if _TransposedWeights.nbytes + n <= _StackRows.CACHE_BYTES:
-            _TransposedWeights.cache[key] = (w._version, wt); _TransposedWeights.nbytes += n
-        elif hit is not None:
-            del _TransposedWeights.cache[key]
+            _TransposedWeights.cache[key] = wt; _TransposedWeights.nbytes += n
         return wt
 
 
 def clear_weight_caches() -> None:
-    """Forget the per-version copies of the weights (stacked projection rows, transposed copies).  They invalidate themselves when a
-    weight is updated in place; a benchmark without an optimizer calls this once per step so that every step pays for its copies as
-    a training step does."""
+    """Drop the per-call copies of the weights (stacked projection rows, transposed copies); `weight_cache.__exit__` calls this."""
     clear_stack_rows_cache()
     _TransposedWeights.cache.clear(); _TransposedWeights.nbytes = 0
 

