@@ -439,7 +439,7 @@ class _HeadRows(torch.autograd.Function):
             logprob_entropy_bwd_raw(logits, next_loc[a:b], lse[a:b], ent[a:b] if ctx.want_entropy else None, g_next[a:b],
                                     g_ent[a:b] if ctx.want_entropy else None, 1.0,
                                     xp[a:b + 1] if ctx.has_forks else None, fork_loc if ctx.has_forks else None, g_fork)
-            if DGRAD_TRANSPOSED_W and W.dtype in (torch.bfloat16, torch.float16) and (b - a) >= 4096 and W.shape[0] % 8 == 0:
+            if DGRAD_TRANSPOSED_W and W.dtype in (torch.bfloat16, torch.float16) and (b - a) >= 4096 and W.shape[0] % 8 == 0 and W.shape[1] % 8 == 0:
                 torch.mm(logits, _TransposedWeights.get(W).t(), out=dh[a:b])        # contraction index contiguous in both operands (see _dgrad)
             else:
                 torch.mm(logits, W, out=dh[a:b])
@@ -872,7 +872,7 @@ def _wgrad(x: torch.Tensor, dy: torch.Tensor, transposed: bool) -> torch.Tensor:
         out = a.t() @ b
     else:
         body = per * S
-        part = torch.bmm(a[:body].view(S, per, a.shape[1]).transpose(1, 2), b[:body].view(S, per, b.shape[1]), out_dtype=torch.float32)
+        part = torch.bmm(a[:body].reshape(S, per, a.shape[1]).transpose(1, 2), b[:body].reshape(S, per, b.shape[1]), out_dtype=torch.float32)
         acc = part.sum(0)
         if body < T:
             acc += torch.mm(a[body:].t(), b[body:], out_dtype=torch.float32)

@@ -84,6 +84,15 @@ class _GradSink:
             self.flat32.add_(self.flat_lo)
             self.flat_lo.zero_()
 
+    def abort(self) -> None:
+        """The walk did not complete (the user's loss_fn raised, out of memory ...): hand the caller's own gradients back untouched."""
+        if not self.active:
+            return
+        for p, o in zip(self.params, self.orig):
+            p.grad = o
+        self.flat_lo = self.flat32 = self.orig = None
+        self.active = False
+
     def finish(self) -> None:
         if not self.active:
             return
@@ -280,6 +289,13 @@ class StackWalk:
 
     # ------------------------------------------------------------------------------------------
     def run(self, loss_fn: Callable):
+        try:
+            return self._run(loss_fn)
+        except BaseException:
+            self.sink.abort()
+            raise
+
+    def _run(self, loss_fn: Callable):
         trie = self.trie
         M = len(trie.lens)
         dev_tokens, starts = trie._dev.tokens, trie._dev.starts

@@ -464,3 +464,28 @@ def test_blockwise_fp32_gradient_sink_on_16bit_parameters():
     r_on = np.mean([mo.grad_ratio(ref[n], on[n]) for n in ref]); r_off = np.mean([mo.grad_ratio(ref[n], off[n]) for n in ref])
     assert r_on <= r_off * 1.02 and r_on < 0.05, (r_on, r_off)
     assert max(mo.grad_ratio(2 * on[n], on2[n]) for n in ref) < 2e-2          # a second call ADDS to the caller's gradient
+
+
+def test_blockwise_walk_hands_the_gradients_back_when_the_loss_callback_raises():
+    """stack_engine._GradSink.abort: for the walk every param.grad is a view of the sink's buffer; if the user's loss_fn raises half-way,
+    the caller's own gradient tensors come back untouched (not dangling views, no partial sums)."""
+    from dynamictreeattn_amd.model import Qwen3TreeLM
+    case = cases.engine_cases()["d16_tree"]; cfg = cases.TINY_CFGS[case["cfg"]]
+    seqs = synth.as_tensors(synth.make_case(case["data"]))
+    m = Qwen3TreeLM(cfg).load_named(mo.init_weights(cfg, seed=case["wseed"])).to(torch.bfloat16)
+    for p in m.parameters():
+        p.grad = torch.full_like(p, 0.5)
+    before = {n: p.grad for n, p in m.named_parameters()}
+    calls = []
+
+    def bad_loss(lp, ent, att):
+        calls.append(1)
+        if len(calls) == 3:
+            raise RuntimeError("user callback failed")
+        return mo.default_loss(lp, ent, att)
+    t = TokenTrie(seqs, _att(len(seqs)), device=CPU); t.backward_permute()
+    e = TreeTrainingEngine(m.config, "cpu", torch.bfloat16, 4096); e.mode = "stack"
+    with pytest.raises(RuntimeError, match="user callback failed"):
+        e.backward(m, t, bad_loss, 8)
+    for n, p in m.named_parameters():
+        assert p.grad is before[n] and bool((p.grad == 0.5).all()), n
