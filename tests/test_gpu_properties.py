@@ -36,3 +36,54 @@ def test_hip_tokentrie_equals_the_oracle(seqs):
 def test_hip_tree_attention_equals_the_oracle_on_random_tries(seqs, heads, order, seed):
     plan, se = ga._trie_case(seqs, order)
     ga._run(plan, se, heads[0], heads[1], torch.bfloat16, seed=seed)
+
+
+@settings(max_examples=12, **COMMON)
+@given(rollouts, st.sampled_from([(2, 1), (4, 2), (6, 2)]), st.sampled_from(["forward", "backward"]), st.integers(0, 3))
+def test_fp32_tree_attention_equals_the_oracle_on_random_tries(seqs, heads, order, seed):
+    """The plain-FMA fp32 kernels (tree_attn_f32.hip) on random tries: out, lse and all three gradients at 2e-5 against the fp32 oracle."""
+    import math
+    import hostmirror
+    from dynamictreeattn_amd import ops, packing
+    from oracle.attn_oracle import tree_attention
+    t = to.TokenTrieOracle([np.asarray(s, dtype=np.int64) for s in seqs]); getattr(t, order + "_permute")()
+    plan = packing.plan_segments(t.lens, t.lcp_lens)
+    _, _, _, se = hostmirror.expand_plan_host(plan)
+    g = torch.Generator().manual_seed(seed)
+    q, k, v, do = (torch.randn(plan.T, H, 128, generator=g) for H in (heads[0], heads[1], heads[1], heads[0]))
+    qr, kr, vr = (x.clone().requires_grad_(True) for x in (q, k, v))
+    o_ref, lse_ref = tree_attention(qr, kr, vr, torch.from_numpy(se).long())
+    (o_ref * do).sum().backward()
+    qd, kd, vd = (x.to(DEV).requires_grad_(True) for x in (q, k, v))
+    meta = ops.meta_from_plan(plan, torch.from_numpy(se).to(DEV), DEV)
+    _, lse, _, _ = ops.attn_fwd_raw(qd.detach(), kd.detach(), vd.detach(), meta, 128 ** -0.5)
+    o = ops.tree_attention(qd, kd, vd, meta)
+    o.backward(do.to(DEV))
+    rel = lambda a, b: float((a.detach().cpu() - b.detach()).norm() / max(float(b.detach().norm()), 1e-3 * b.numel() ** 0.5))
+    assert rel(o, o_ref) <= 2e-5 and rel(qd.grad, qr.grad) <= 2e-5 and rel(kd.grad, kr.grad) <= 2e-5 and rel(vd.grad, vr.grad) <= 2e-5
+    assert (lse.cpu().t() * math.log(2.0) - lse_ref.detach()).abs().max() <= 2e-5
+
+
+@settings(max_examples=25, **COMMON)
+@given(st.integers(1, 40), st.integers(1, 40), st.sampled_from([torch.bfloat16, torch.float32]), st.integers(0, 5))
+def test_transpose_kernel_on_random_shapes(rb, cb, dtype, seed):
+    """dta_transpose on ragged tile counts: rows / cols any multiple of the 16-byte vector (8 or 4 elements)."""
+    from dynamictreeattn_amd import ops
+    v = 8 if dtype == torch.bfloat16 else 4
+    R, C = rb * v, cb * v
+    x = torch.randn(R, C, generator=torch.Generator().manual_seed(seed)).to(dtype).to(DEV)
+    assert torch.equal(ops.transpose_2d(x), x.t().contiguous())
+
+
+@settings(max_examples=10, **COMMON)
+@given(st.integers(33, 80), st.sampled_from([(1024, 512), (256, 768), (512, 1024)]), st.booleans(), st.integers(0, 3))
+def test_split_k_weight_gradient_equals_the_single_gemm(t256, shape, transposed, seed):
+    """ops._wgrad: the 4-slice batched GEMM with fp32 partials (+ the remainder rows) against the plain product in fp32."""
+    from dynamictreeattn_amd import ops
+    T, (out_f, in_f) = 256 * t256, shape
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(T, in_f, generator=g).bfloat16().to(DEV); dy = torch.randn(T, out_f, generator=g).bfloat16().to(DEV)
+    got = ops._wgrad(x, dy, transposed).float()
+    ref = dy.float().t() @ x.float()
+    assert got.shape == ref.shape
+    assert float((got - ref).norm() / ref.norm()) <= 3e-3                  # one bf16 rounding of the result
