@@ -212,7 +212,9 @@ def test_fp32_qwen3_0p6b_config1_vs_the_reference_at_full_model_size():
     lt = TreeTrainingEngine(m.config, DEV, F32, 512).backward(m, t, mo.default_loss, 2048)
     gt = {n: p.grad.clone() for n, p in m.named_parameters()}
     assert abs(lt - ref["loss_tree"]) <= 1e-5 * abs(ref["loss_tree"]), (lt, ref["loss_tree"])
-    worst_norm = max(abs(float(g.norm()) - ref["norm_dense"][n]) / (ref["norm_dense"][n] + 1e-12) for n, g in gt.items())
+    devs = sorted(((abs(float(g.norm()) - ref["norm_dense"][n]) / (ref["norm_dense"][n] + 1e-12), n, float(g.norm()), ref["norm_dense"][n]) for n, g in gt.items()), reverse=True)
+    print("largest gradient-norm deviations from the reference:", [(f"{d:.2e}", n, f"{a:.6e}", f"{b:.6e}") for d, n, a, b in devs[:4]])
+    worst_norm = devs[0][0]
     sample = gt["model.embed_tokens.weight"][seqs[0][:8].to(DEV)][:, :16].cpu()
     assert worst_norm <= 1e-4, worst_norm
     assert torch.allclose(sample, torch.tensor(ref["embed_grad_sample"]), rtol=1e-4, atol=1e-7)
