@@ -198,29 +198,36 @@ def test_fp32_huggingface_model_through_the_engine():
 
 
 def test_fp32_qwen3_0p6b_config1_vs_the_reference_at_full_model_size():
-    """BASELINE config 1 at FULL model size in fp32 on the HIP path (Qwen3-0.6B dims, 310 tensors, seeded weights): the loss the REFERENCE
-    engine computed on CPU for the same weights and batch (tests/golden/qwen3_0p6b_config1.json, scripts/make_golden.py big:
-    53.315989) to 1e-5, every parameter's gradient NORM against the reference's dense run to 1e-4, the recorded embedding-gradient sample
-    to 1e-4, and tree vs dense on the GPU per parameter to 1e-5 (the reference measured 1.5e-6 for its own pair)."""
+    """BASELINE config 1 at FULL model size in fp32 on the HIP path (Qwen3-0.6B dims, 310 tensors, seeded weights):
+    * the loss the REFERENCE engine computed on CPU for the same weights and batch (tests/golden/qwen3_0p6b_config1.json: 53.315989): 1e-5;
+    * tree vs dense on the GPU, per parameter: 1e-5 (the reference measured 1.5e-6 for its own pair);
+    * every parameter's gradient NORM against the EXACT value (float64 run of the oracle, tests/golden/qwen3_0p6b_config1_norms_f64.json,
+      scripts/make_golden.py big64): 2e-5;
+    * against the reference's own fp32 norms only 1e-3: the reference's CPU fp32 run is itself 6.0e-4 away from the exact embedding-gradient
+      norm (10.247566 recorded, 10.253768 exact) and 2e-4 on the gate projections - long fp32 sums - while the HIP path lands on the exact values."""
     import json
     cfg = synth.QWEN3_0P6B
     m = Qwen3TreeLM.from_named(cfg, mo.init_weights(cfg, seed=0), DEV, F32)
     seqs = synth.as_tensors(synth.config1(0, cfg["vocab_size"]))
     att = lambda: [{"w_logprobs": -1.0, "w_entropy": 0.1} for _ in seqs]
     ref = json.load(open(os.path.join(GOLD, "qwen3_0p6b_config1.json")))
+    exact = json.load(open(os.path.join(GOLD, "qwen3_0p6b_config1_norms_f64.json")))
     t = TokenTrie(seqs, att()); t.backward_permute()
     lt = TreeTrainingEngine(m.config, DEV, F32, 512).backward(m, t, mo.default_loss, 2048)
     gt = {n: p.grad.clone() for n, p in m.named_parameters()}
-    assert abs(lt - ref["loss_tree"]) <= 1e-5 * abs(ref["loss_tree"]), (lt, ref["loss_tree"])
-    devs = sorted(((abs(float(g.norm()) - ref["norm_dense"][n]) / (ref["norm_dense"][n] + 1e-12), n, float(g.norm()), ref["norm_dense"][n]) for n, g in gt.items()), reverse=True)
-    print("largest gradient-norm deviations from the reference:", [(f"{d:.2e}", n, f"{a:.6e}", f"{b:.6e}") for d, n, a, b in devs[:4]])
-    worst_norm = devs[0][0]
-    sample = gt["model.embed_tokens.weight"][seqs[0][:8].to(DEV)][:, :16].cpu()
-    assert worst_norm <= 1e-4, worst_norm
-    assert torch.allclose(sample, torch.tensor(ref["embed_grad_sample"]), rtol=1e-4, atol=1e-7)
     m.zero_grad(set_to_none=True)
     ld = dense.backward(m, seqs, att(), mo.default_loss)
-    worst = max(((n, mo.grad_ratio(p.grad.cpu(), gt[n].cpu())) for n, p in m.named_parameters()), key=lambda kv: kv[1])
-    print(f"fp32 Qwen3-0.6B config 1: loss tree {lt:.6f} dense {ld:.6f} (reference {ref['loss_tree']:.6f}); worst norm deviation from the reference {worst_norm:.2e}; "
-          f"tree vs dense worst |dg|/|g| {worst[1]:.2e} ({worst[0]})")
-    assert abs(ld - ref["loss_dense"]) <= 1e-5 * abs(ld) and worst[1] <= 1e-5, worst
+    gd = {n: p.grad.clone() for n, p in m.named_parameters()}
+    dev_of = lambda gs, tab: sorted(((abs(float(g.norm()) - tab[n]) / (tab[n] + 1e-12), n) for n, g in gs.items()), reverse=True)
+    vs_exact, vs_ref = dev_of(gt, exact), dev_of(gt, ref["norm_dense"])
+    ref_vs_exact = max(abs(ref["norm_dense"][n] - exact[n]) / exact[n] for n in exact)
+    worst = max(((n, mo.grad_ratio(gd[n].cpu(), gt[n].cpu())) for n in gt), key=lambda kv: kv[1])
+    sample = gt["model.embed_tokens.weight"][seqs[0][:8].to(DEV)][:, :16].cpu()
+    print(f"fp32 Qwen3-0.6B config 1: loss tree {lt:.6f} dense {ld:.6f} (reference {ref['loss_tree']:.6f}); gradient norms vs the exact (float64) values: worst "
+          f"{vs_exact[0][0]:.2e} ({vs_exact[0][1]}); vs the reference's fp32 run: worst {vs_ref[0][0]:.2e} ({vs_ref[0][1]}) - the reference itself is "
+          f"{ref_vs_exact:.2e} from exact; tree vs dense worst |dg|/|g| {worst[1]:.2e} ({worst[0]})")
+    assert abs(lt - ref["loss_tree"]) <= 1e-5 * abs(ref["loss_tree"]) and abs(ld - ref["loss_dense"]) <= 1e-5 * abs(ld)
+    assert worst[1] <= 1e-5, worst
+    assert vs_exact[0][0] <= 2e-5, vs_exact[:3]
+    assert vs_ref[0][0] <= 1e-3, vs_ref[:3]
+    assert torch.allclose(sample, torch.tensor(ref["embed_grad_sample"]), rtol=2e-3, atol=1e-7)
