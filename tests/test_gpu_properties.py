@@ -87,3 +87,37 @@ def test_split_k_weight_gradient_equals_the_single_gemm(t256, shape, transposed,
     ref = dy.float().t() @ x.float()
     assert got.shape == ref.shape
     assert float((got - ref).norm() / ref.norm()) <= 3e-3                  # one bf16 rounding of the result
+
+
+@settings(max_examples=10, **COMMON)
+@given(rollouts, st.sampled_from(["packed", "stack"]), st.sampled_from([7, 16, 2048]), st.sampled_from(["backward", "forward", "sorted"]), st.integers(0, 2))
+def test_fp32_engine_equals_the_reference_schedule_on_random_tries(seqs, mode, block, order, wseed):
+    """The whole hot path in fp32 on random rollouts (duplicates, prefixes of each other, single sequences, ...): HIP TokenTrie -> permute ->
+    engine.backward (one packed pass or the block-wise walk with small blocks: fork picks, pending picks, cut tails) against the ORACLE's
+    restatement of the reference's push / pop schedule on the same leaf order - loss and every parameter gradient at 1e-4 (fp32 leaves four
+    orders of magnitude below what a bf16 comparison can resolve, so indexing or bookkeeping slips cannot hide in rounding noise)."""
+    import cases
+    from dynamictreeattn_amd.model import Qwen3TreeLM
+    from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine
+    from oracle import model_oracle as mo
+    cfg = cases.TINY_CFGS["d128"]
+    w = mo.init_weights(cfg, seed=10 + wseed)
+    att = lambda: [{"w_logprobs": -1.0 - 0.01 * i, "w_entropy": 0.1 + 0.003 * i} for i in range(len(seqs))]
+    t = TokenTrie([torch.tensor(s, dtype=torch.int64) for s in seqs], att(), device=DEV)
+    o = to.TokenTrieOracle([np.asarray(s, dtype=np.int64) for s in seqs], att())
+    if order != "sorted":
+        getattr(t, order + "_permute")(); getattr(o, order + "_permute")()
+    wo = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    loss_o = mo.StackEngineOracle(cfg, wo, max(map(len, seqs))).backward(o, mo.default_loss, block)
+    m = Qwen3TreeLM.from_named(cfg, w, DEV, torch.float32)
+    e = TreeTrainingEngine(m.config, DEV, torch.float32, max(map(len, seqs))); e.mode = mode
+    if mode == "stack":
+        e._stack_block_rows = lambda *a: block
+    loss = e.backward(m, t, mo.default_loss, block)
+    assert abs(loss - float(loss_o)) <= 1e-5 * max(abs(float(loss_o)), 1.0), (loss, float(loss_o))
+    for n, p in m.named_parameters():
+        go = wo[n].grad
+        if go is None or float(go.norm()) == 0.0:
+            assert p.grad is None or float(p.grad.norm()) <= 1e-6, n
+        else:
+            assert mo.grad_ratio(go, p.grad.cpu()) <= 1e-4, (n, mode, block, order)
