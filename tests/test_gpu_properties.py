@@ -89,8 +89,11 @@ def test_split_k_weight_gradient_equals_the_single_gemm(t256, shape, transposed,
     assert float((got - ref).norm() / ref.norm()) <= 3e-3                  # one bf16 rounding of the result
 
 
+rollouts2 = st.lists(st.lists(st.integers(0, 3), min_size=2, max_size=70), min_size=1, max_size=14)      # >= 2 tokens: run.py's loss is a mean over len-1 logprobs
+
+
 @settings(max_examples=10, **COMMON)
-@given(rollouts, st.sampled_from(["packed", "stack"]), st.sampled_from([7, 16, 2048]), st.sampled_from(["backward", "forward", "sorted"]), st.integers(0, 2))
+@given(rollouts2, st.sampled_from(["packed", "stack"]), st.sampled_from([7, 16, 2048]), st.sampled_from(["backward", "forward", "sorted"]), st.integers(0, 2))
 def test_fp32_engine_equals_the_reference_schedule_on_random_tries(seqs, mode, block, order, wseed):
     """The whole hot path in fp32 on random rollouts (duplicates, prefixes of each other, single sequences, ...): HIP TokenTrie -> permute ->
     engine.backward (one packed pass or the block-wise walk with small blocks: fork picks, pending picks, cut tails) against the ORACLE's
@@ -115,9 +118,10 @@ def test_fp32_engine_equals_the_reference_schedule_on_random_tries(seqs, mode, b
         e._stack_block_rows = lambda *a: block
     loss = e.backward(m, t, mo.default_loss, block)
     assert abs(loss - float(loss_o)) <= 1e-5 * max(abs(float(loss_o)), 1.0), (loss, float(loss_o))
+    gmax = max(float(v.grad.norm()) for v in wo.values() if v.grad is not None)
     for n, p in m.named_parameters():
-        go = wo[n].grad
-        if go is None or float(go.norm()) == 0.0:
-            assert p.grad is None or float(p.grad.norm()) <= 1e-6, n
-        else:
-            assert mo.grad_ratio(go, p.grad.cpu()) <= 1e-4, (n, mode, block, order)
+        go = wo[n].grad if wo[n].grad is not None else torch.zeros_like(wo[n])
+        gp = p.grad.cpu() if p.grad is not None else torch.zeros_like(go)
+        # relative to the parameter's own gradient, with a floor relative to the largest gradient of the model (a 2-token sequence leaves
+        # the q projection a gradient of 1e-9: its rounding noise is not an error)
+        assert float((gp - go).norm()) <= 1e-4 * float(go.norm()) + 1e-6 * gmax, (n, mode, block, order, float((gp - go).norm()), float(go.norm()), gmax)
