@@ -92,7 +92,7 @@ def test_split_k_weight_gradient_equals_the_single_gemm(t256, shape, transposed,
 rollouts2 = st.lists(st.lists(st.integers(0, 3), min_size=2, max_size=70), min_size=1, max_size=14)      # >= 2 tokens: run.py's loss is a mean over len-1 logprobs
 
 
-@settings(max_examples=10, **COMMON)
+@settings(max_examples=30, **COMMON)
 @given(rollouts2, st.sampled_from(["packed", "stack"]), st.sampled_from([7, 16, 2048]), st.sampled_from(["backward", "forward", "sorted"]), st.integers(0, 2))
 def test_fp32_engine_equals_the_reference_schedule_on_random_tries(seqs, mode, block, order, wseed):
     """The whole hot path in fp32 on random rollouts (duplicates, prefixes of each other, single sequences, ...): HIP TokenTrie -> permute ->
