@@ -31,10 +31,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---------------------------------------------------------------------------------------------
 // RMSNorm over rows of H (H % 8 == 0; forward: any H, backward: H <= 8192).  One wave per row, 4 rows per workgroup, grid-stride.
 // ---------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, int NA>
 __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* __restrict__ x_, const void* __restrict__ delta_, const void* __restrict__ w_,
                                                           void* __restrict__ xout_, void* __restrict__ y_,
                                                           float* __restrict__ rstd, int R, int H, float eps) {
+  // NA > 0: the row (H <= 512*NA elements) stays in registers between the sum-of-squares pass and the scaling pass - ONE read of x (and of
+  // delta) per row; NA == 0: any H, second pass re-reads the row (L2-hot).
   using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const e* w = reinterpret_cast<const e*>(w_);
@@ -43,41 +45,77 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const void* __restrict
     const e* x = reinterpret_cast<const e*>(x_) + (int64_t)row * H;
     e* y = reinterpret_cast<e*>(y_) + (int64_t)row * H;
     float ss = 0.f;
-    if (delta_) {                                      // residual stream update fused in: x_out = x + delta (rounded), then normalised
-      const e* dl = reinterpret_cast<const e*>(delta_) + (int64_t)row * H;
-      e* xo = reinterpret_cast<e*>(xout_) + (int64_t)row * H;
-      for (int i = lane; i < nv; i += 64) {
-        const v8 v = *reinterpret_cast<const v8*>(x + 8 * i); const v8 d = *reinterpret_cast<const v8*>(dl + 8 * i);
-        v8 o;
+    if constexpr (NA > 0) {
+      v8 keep[NA];
+      const e* dl = delta_ ? reinterpret_cast<const e*>(delta_) + (int64_t)row * H : nullptr;
+      e* xo = delta_ ? reinterpret_cast<e*>(xout_) + (int64_t)row * H : nullptr;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { o[j] = (e)((float)v[j] + (float)d[j]); const float f = (float)o[j]; ss = __builtin_fmaf(f, f, ss); }
-        *reinterpret_cast<v8*>(xo + 8 * i) = o;
+      for (int a = 0; a < NA; ++a) {
+        const int i = lane + 64 * a;
+        if (i < nv) {
+          v8 v = *reinterpret_cast<const v8*>(x + 8 * i);
+          if (dl) {
+            const v8 d = *reinterpret_cast<const v8*>(dl + 8 * i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (e)((float)v[j] + (float)d[j]);
+            *reinterpret_cast<v8*>(xo + 8 * i) = v;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; ss = __builtin_fmaf(f, f, ss); }
+          keep[a] = v;
+        }
       }
-      x = xo;                                          // second pass re-reads the wave's own (L1/L2-hot) row
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      ss = wave_sum(ss);
+      const float r = __builtin_amdgcn_rsqf(ss / (float)H + eps);
+      if (lane == 0) rstd[row] = r;
+#pragma unroll
+      for (int a = 0; a < NA; ++a) {
+        const int i = lane + 64 * a;
+        if (i < nv) {
+          const v8 wv = *reinterpret_cast<const v8*>(w + 8 * i);
+          v8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const e t = (e)((float)keep[a][j] * r); o[j] = (e)((float)wv[j] * (float)t); }
+          *reinterpret_cast<v8*>(y + 8 * i) = o;
+        }
+      }
     } else {
+      if (delta_) {                                      // residual stream update fused in: x_out = x + delta (rounded), then normalised
+        const e* dl = reinterpret_cast<const e*>(delta_) + (int64_t)row * H;
+        e* xo = reinterpret_cast<e*>(xout_) + (int64_t)row * H;
+        for (int i = lane; i < nv; i += 64) {
+          const v8 v = *reinterpret_cast<const v8*>(x + 8 * i); const v8 d = *reinterpret_cast<const v8*>(dl + 8 * i);
+          v8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { o[j] = (e)((float)v[j] + (float)d[j]); const float f = (float)o[j]; ss = __builtin_fmaf(f, f, ss); }
+          *reinterpret_cast<v8*>(xo + 8 * i) = o;
+        }
+        x = xo;                                          // second pass re-reads the wave's own (L1/L2-hot) row
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      } else {
+        for (int i = lane; i < nv; i += 64) {
+          const v8 v = *reinterpret_cast<const v8*>(x + 8 * i);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; ss = __builtin_fmaf(f, f, ss); }
+        }
+      }
+      ss = wave_sum(ss);
+      const float r = __builtin_amdgcn_rsqf(ss / (float)H + eps);
+      if (lane == 0) rstd[row] = r;
       for (int i = lane; i < nv; i += 64) {
         const v8 v = *reinterpret_cast<const v8*>(x + 8 * i);
+        const v8 wv = *reinterpret_cast<const v8*>(w + 8 * i);
+        v8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; ss = __builtin_fmaf(f, f, ss); }
+        for (int j = 0; j < 8; ++j) { const e t = (e)((float)v[j] * r); o[j] = (e)((float)wv[j] * (float)t); }
+        *reinterpret_cast<v8*>(y + 8 * i) = o;
       }
-    }
-    ss = wave_sum(ss);
-    const float r = __builtin_amdgcn_rsqf(ss / (float)H + eps);
-    if (lane == 0) rstd[row] = r;
-    for (int i = lane; i < nv; i += 64) {
-      const v8 v = *reinterpret_cast<const v8*>(x + 8 * i);
-      const v8 wv = *reinterpret_cast<const v8*>(w + 8 * i);
-      v8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const e t = (e)((float)v[j] * r); o[j] = (e)((float)wv[j] * (float)t); }
-      *reinterpret_cast<v8*>(y + 8 * i) = o;
     }
   }
 }
 
 // dx = r·(dt − t̂·mean(dt·t̂)), dt = dy·w, t̂ = x·r ;  dw partial per workgroup: Σ_rows dy·t̂.
-// NA = v8 groups per lane held in registers: 8 (H <= 4096) or 16 (H <= 8192: Qwen3-14B/32B hidden 5120).
+// NA = v8 groups per lane (dw accumulators in registers): 2/4/8 for H <= 1024/2048/4096, 16 for H <= 8192 (Qwen3-14B/32B hidden 5120).
 template <int DT, int NA>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_, const void* __restrict__ dy_,
                                                           const void* __restrict__ dres_,
@@ -89,6 +127,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict
   const e* w = reinterpret_cast<const e*>(w_);
   const int nv = H >> 3;
   const int per_lane = (nv + 63) >> 6;                      // <= NA
+  constexpr bool KEEP = NA * sizeof(v8) <= 128;             // x and dy of the row stay in registers between the two passes (<= 64 VGPRs)
   float acc[NA][8];
 #pragma unroll
   for (int a = 0; a < NA; ++a)
@@ -100,6 +139,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict
     e* dx = reinterpret_cast<e*>(dx_) + (int64_t)row * H;
     const float r = rstd[row];
     float dot = 0.f;
+    v8 kx[KEEP ? NA : 1], kg[KEEP ? NA : 1];
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
       const int i = lane + 64 * a;
@@ -108,6 +148,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict
         const v8 wv = *reinterpret_cast<const v8*>(w + 8 * i);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float t = (float)v[j] * r; const float gg = (float)g[j]; dot = __builtin_fmaf(gg * (float)wv[j], t, dot); acc[a][j] = __builtin_fmaf(gg, t, acc[a][j]); }
+        if constexpr (KEEP) { kx[a] = v; kg[a] = g; }
       }
     }
     dot = wave_sum(dot) / (float)H;
@@ -115,7 +156,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict
     for (int a = 0; a < NA; ++a) {
       const int i = lane + 64 * a;
       if (a < per_lane && i < nv) {
-        const v8 v = *reinterpret_cast<const v8*>(x + 8 * i); const v8 g = *reinterpret_cast<const v8*>(dy + 8 * i);
+        v8 v, g;
+        if constexpr (KEEP) { v = kx[a]; g = kg[a]; }
+        else { v = *reinterpret_cast<const v8*>(x + 8 * i); g = *reinterpret_cast<const v8*>(dy + 8 * i); }
         const v8 wv = *reinterpret_cast<const v8*>(w + 8 * i);
         v8 o;
         if (dres_) {                                   // gradient arriving on the residual stream is added here (one pass less)
@@ -363,7 +406,19 @@ extern "C" int dta_rmsnorm_fwd(const void* x, const void* delta, const void* w, 
   if (!x || !w || !y || !rstd || R <= 0 || H <= 0 || ((delta != nullptr) != (x_out != nullptr))) return DTA_EINVAL;
   if (!row_dtype_ok(dtype) || H % 8) return DTA_EUNSUPPORTED;
   if (!al16(x) || !al16(w) || !al16(y) || (delta && (!al16(delta) || !al16(x_out)))) return DTA_EALIGN;
-  DTA_DISPATCH(rmsnorm_fwd_kernel, row_blocks(R, 4, 4096), x, delta, w, x_out, y, rstd, R, H, eps);
+  hipStream_t st_ = static_cast<hipStream_t>(stream);
+  DTA_REFUSE_IF_PRIOR_ERROR();
+  const dim3 grid(row_blocks(R, 4, 8192)), block(256);
+#define DTA_RMS_FWD(NA_)                                                                                                       \
+  do { if (dtype == DTA_BF16) hipLaunchKernelGGL((rmsnorm_fwd_kernel<DTA_BF16, NA_>), grid, block, 0, st_, x, delta, w, x_out, y, rstd, R, H, eps); \
+       else if (dtype == DTA_F16) hipLaunchKernelGGL((rmsnorm_fwd_kernel<DTA_F16, NA_>), grid, block, 0, st_, x, delta, w, x_out, y, rstd, R, H, eps); \
+       else hipLaunchKernelGGL((rmsnorm_fwd_kernel<DTA_F32, NA_>), grid, block, 0, st_, x, delta, w, x_out, y, rstd, R, H, eps); } while (0)
+  if (H <= 1024) DTA_RMS_FWD(2);                 // rows of up to 1 024 / 2 048 / 4 096 elements stay in registers between the two passes
+  else if (H <= 2048) DTA_RMS_FWD(4);
+  else if (H <= 4096) DTA_RMS_FWD(8);
+  else DTA_RMS_FWD(0);
+#undef DTA_RMS_FWD
+  return DTA_LAUNCH_STATUS();
 }
 
 /* dw_partial: float [dta_rmsnorm_bwd_blocks(R), H]; the caller sums it over dim 0. */
@@ -376,15 +431,15 @@ extern "C" int dta_rmsnorm_bwd(const void* x, const void* w, const void* dy, con
   hipStream_t st_ = static_cast<hipStream_t>(stream);
   DTA_REFUSE_IF_PRIOR_ERROR();
   const dim3 grid(row_blocks(R, 4, 2048)), block(256);
-  if (H <= 4096) {
-    if (dtype == DTA_BF16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_BF16, 8>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
-    else if (dtype == DTA_F16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F16, 8>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
-    else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F32, 8>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
-  } else {
-    if (dtype == DTA_BF16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_BF16, 16>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
-    else if (dtype == DTA_F16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F16, 16>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
-    else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F32, 16>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H);
-  }
+#define DTA_RMS_BWD(NA_)                                                                                                       \
+  do { if (dtype == DTA_BF16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_BF16, NA_>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H); \
+       else if (dtype == DTA_F16) hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F16, NA_>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H); \
+       else hipLaunchKernelGGL((rmsnorm_bwd_kernel<DTA_F32, NA_>), grid, block, 0, st_, x, w, dy, dres, rstd, dx, dw_partial, R, H); } while (0)
+  if (H <= 1024) DTA_RMS_BWD(2);                 // NA = 16-byte groups per lane; the row stays in registers where that fits (see KEEP)
+  else if (H <= 2048) DTA_RMS_BWD(4);
+  else if (H <= 4096) DTA_RMS_BWD(8);
+  else DTA_RMS_BWD(16);
+#undef DTA_RMS_BWD
   return DTA_LAUNCH_STATUS();
 }
 

@@ -31,7 +31,7 @@ def _pair(fn_gpu, fn_ref, inputs, dtype):
             assert _rel(a.grad, b.grad) <= (1e-2 if a.dim() == 1 else tol), a.shape
 
 
-@pytest.mark.parametrize("R,H,dtype", [(1, 8, torch.bfloat16), (37, 64, torch.bfloat16), (1000, 1024, torch.bfloat16), (515, 2560, torch.float16), (9, 4096, torch.bfloat16),
+@pytest.mark.parametrize("R,H,dtype", [(1, 8, torch.bfloat16), (37, 64, torch.bfloat16), (1000, 1024, torch.bfloat16), (33, 1000, torch.bfloat16), (40, 2048, torch.float16), (515, 2560, torch.float16), (9, 4096, torch.bfloat16),
                                        (301, 5120, torch.bfloat16), (17, 8192, torch.float16)])      # 5120 = Qwen3-14B / 32B hidden (exp/exp_dp.py:9)
 def test_rmsnorm(R, H, dtype):
     g = torch.Generator().manual_seed(R + H)
