@@ -32,6 +32,7 @@ _PROTOS = {
     "dta_swiglu_fwd": ([_vp] * 3 + [_i64, _i32, _i64, _i32, _vp], C.c_int),
     "dta_swiglu_bwd": ([_vp] * 5 + [_i64, _i32, _i64, _i64, _i32, _vp], C.c_int),
     "dta_transpose": ([_vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp], C.c_int),
+    "dta_sum_slabs": ([_vp, _i64, _i64, _i64, _vp, _vp, _i32, _vp], C.c_int),
 }
 EXPORTS = tuple(_PROTOS)
 _ERR = {-1: "DTA_EINVAL", -2: "DTA_EUNSUPPORTED", -3: "DTA_EALIGN", -4: "DTA_ELAUNCH", -5: "DTA_EPRIOR"}

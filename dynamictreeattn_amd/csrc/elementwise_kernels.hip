@@ -197,93 +197,117 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const void* __restrict
 // q/k head-norm + RoPE.  x: [T, NH, 128]; 16 lanes own one head (8 elements each); a wave = 4 heads.
 // cs: [T, 128] float = {cos[0..63], sin[0..63]} of the token's depth.  w == NULL: RoPE only.
 // ---------------------------------------------------------------------------------------------
-template <int DT>
+// HPL = heads of ONE token per 16-lane group (4 when NH % 4 == 0): the token's cos/sin values - 64 bytes per lane, four times the 16 bytes
+// of x - are fetched once and reused, and HPL independent 16-byte loads are in flight per lane.
+template <int DT, int HPL>
 __global__ __launch_bounds__(256) void qk_norm_rope_fwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_, const float* __restrict__ cs,
-                                                               void* __restrict__ y_, float* __restrict__ rstd, int64_t n_heads_total, int NH,
+                                                               void* __restrict__ y_, float* __restrict__ rstd, int64_t n_units, int NH,
                                                                int64_t x_st, float eps) {
   using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
   const int lane = threadIdx.x & 63, sub = lane & 15;
-  const int64_t hid = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);      // global (token, head) index
-  if (hid >= n_heads_total) return;
-  const int64_t tok = hid / NH; const int head = (int)(hid - tok * NH);
-  const e* x = reinterpret_cast<const e*>(x_) + tok * x_st + (int64_t)head * 128 + 8 * sub;
-  e* y = reinterpret_cast<e*>(y_) + hid * 128 + 8 * sub;
-  const v8 v = *reinterpret_cast<const v8*>(x);
-  float a[8];
-  if (w_) {
-    float ss = 0.f;
+  const int64_t unit = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);     // global (token, head group) index
+  if (unit >= n_units) return;
+  const int groups = NH / HPL;
+  const int64_t tok = unit / groups; const int head0 = (int)(unit - tok * groups) * HPL;
+  const e* x = reinterpret_cast<const e*>(x_) + tok * x_st + (int64_t)head0 * 128 + 8 * sub;
+  const int64_t hid0 = tok * NH + head0;
+  e* y = reinterpret_cast<e*>(y_) + hid0 * 128 + 8 * sub;
+  v8 v[HPL];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; ss = __builtin_fmaf(f, f, ss); }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    const float r = __builtin_amdgcn_rsqf(ss * (1.f / 128.f) + eps);
-    if (sub == 0) rstd[hid] = r;
-    const v8 wv = *reinterpret_cast<const v8*>(reinterpret_cast<const e*>(w_) + 8 * sub);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const e t = (e)((float)v[j] * r); a[j] = (float)(e)((float)wv[j] * (float)t); }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = (float)v[j];
-  }
-  // rotate_half partner: element i <-> i ± 64  == lane sub ^ 8 of the same head group
+  for (int h = 0; h < HPL; ++h) v[h] = *reinterpret_cast<const v8*>(x + h * 128);
+  // rotate_half partner: element i <-> i +- 64  == lane sub ^ 8 of the same head
   const float* c = cs + tok * 128 + 8 * (sub & 7);
-  v8 o;
+  float cj[8], sj[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float other = __shfl_xor(a[j], 8);
-    const float cj = c[j], sj = c[64 + j];
-    o[j] = (e)(sub < 8 ? a[j] * cj - other * sj : a[j] * cj + other * sj);
+  for (int j = 0; j < 8; ++j) { cj[j] = c[j]; sj[j] = sub < 8 ? -c[64 + j] : c[64 + j]; }
+  v8 wv;
+  if (w_) wv = *reinterpret_cast<const v8*>(reinterpret_cast<const e*>(w_) + 8 * sub);
+#pragma unroll
+  for (int h = 0; h < HPL; ++h) {
+    float a[8];
+    if (w_) {
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)v[h][j]; ss = __builtin_fmaf(f, f, ss); }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+      const float r = __builtin_amdgcn_rsqf(ss * (1.f / 128.f) + eps);
+      if (sub == 0) rstd[hid0 + h] = r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const e t = (e)((float)v[h][j] * r); a[j] = (float)(e)((float)wv[j] * (float)t); }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = (float)v[h][j];
+    }
+    v8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float other = __shfl_xor(a[j], 8);
+      o[j] = (e)(a[j] * cj[j] + other * sj[j]);
+    }
+    *reinterpret_cast<v8*>(y + h * 128) = o;
   }
-  *reinterpret_cast<v8*>(y) = o;
 }
 
-template <int DT>
+template <int DT, int HPL>
 __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_, const float* __restrict__ cs,
                                                                const void* __restrict__ dy_, const float* __restrict__ rstd,
-                                                               void* __restrict__ dx_, float* __restrict__ dw_part, int64_t n_heads_total, int NH,
+                                                               void* __restrict__ dx_, float* __restrict__ dw_part, int64_t n_units, int NH,
                                                                int64_t x_st, int64_t dy_st_t, int64_t dy_st_h, int64_t dx_st) {
   using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
   __shared__ float red[256 * 8];
   const int lane = threadIdx.x & 63, sub = lane & 15;
+  const int groups = NH / HPL;
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int64_t base = (int64_t)blockIdx.x * 16; base < n_heads_total; base += (int64_t)gridDim.x * 16) {
-    const int64_t hid = base + (threadIdx.x >> 6) * 4 + (lane >> 4);
-    const bool live = hid < n_heads_total;
-    const int64_t hc = live ? hid : n_heads_total - 1;
-    const int64_t tok = hc / NH; const int head = (int)(hc - tok * NH);
-    const e* dy = reinterpret_cast<const e*>(dy_) + tok * dy_st_t + (int64_t)head * dy_st_h + 8 * sub;
-    const v8 g = *reinterpret_cast<const v8*>(dy);
-    const float* c = cs + tok * 128 + 8 * (sub & 7);
-    float da[8];
+  v8 wv;
+  if (w_) wv = *reinterpret_cast<const v8*>(reinterpret_cast<const e*>(w_) + 8 * sub);
+  for (int64_t base = (int64_t)blockIdx.x * 16; base < n_units; base += (int64_t)gridDim.x * 16) {
+    const int64_t unit = base + (threadIdx.x >> 6) * 4 + (lane >> 4);
+    const bool live = unit < n_units;
+    const int64_t uc = live ? unit : n_units - 1;
+    const int64_t tok = uc / groups; const int head0 = (int)(uc - tok * groups) * HPL;
+    const e* dy = reinterpret_cast<const e*>(dy_) + tok * dy_st_t + (int64_t)head0 * dy_st_h + 8 * sub;
+    v8 g[HPL], v[HPL];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float gj = (float)g[j];
-      const float other = __shfl_xor(gj, 8);
-      const float cj = c[j], sj = c[64 + j];
-      da[j] = sub < 8 ? gj * cj + other * sj : gj * cj - other * sj;
-    }
-    e* dx = reinterpret_cast<e*>(dx_) + tok * dx_st + (int64_t)head * 128 + 8 * sub;
-    v8 o;
+    for (int h = 0; h < HPL; ++h) g[h] = *reinterpret_cast<const v8*>(dy + h * dy_st_h);
     if (w_) {
-      const e* x = reinterpret_cast<const e*>(x_) + tok * x_st + (int64_t)head * 128 + 8 * sub;
-      const v8 v = *reinterpret_cast<const v8*>(x);
-      const v8 wv = *reinterpret_cast<const v8*>(reinterpret_cast<const e*>(w_) + 8 * sub);
-      const float r = rstd[hc];
-      float dot = 0.f, t[8];
+      const e* x = reinterpret_cast<const e*>(x_) + tok * x_st + (int64_t)head0 * 128 + 8 * sub;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { t[j] = (float)v[j] * r; dot = __builtin_fmaf(da[j] * (float)wv[j], t[j], dot); if (live) acc[j] = __builtin_fmaf(da[j], t[j], acc[j]); }
-#pragma unroll
-      for (int o2 = 8; o2 > 0; o2 >>= 1) dot += __shfl_xor(dot, o2);
-      dot *= (1.f / 128.f);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (e)(r * (da[j] * (float)wv[j] - t[j] * dot));
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (e)da[j];
+      for (int h = 0; h < HPL; ++h) v[h] = *reinterpret_cast<const v8*>(x + h * 128);
     }
-    if (live) *reinterpret_cast<v8*>(dx) = o;
+    const float* c = cs + tok * 128 + 8 * (sub & 7);
+    float cj[8], sj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cj[j] = c[j]; sj[j] = sub < 8 ? c[64 + j] : -c[64 + j]; }
+    e* dx = reinterpret_cast<e*>(dx_) + tok * dx_st + (int64_t)head0 * 128 + 8 * sub;
+#pragma unroll
+    for (int h = 0; h < HPL; ++h) {
+      float da[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gj = (float)g[h][j];
+        const float other = __shfl_xor(gj, 8);
+        da[j] = gj * cj[j] + other * sj[j];
+      }
+      v8 o;
+      if (w_) {
+        const float r = rstd[tok * NH + head0 + h];
+        float dot = 0.f, t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t[j] = (float)v[h][j] * r; dot = __builtin_fmaf(da[j] * (float)wv[j], t[j], dot); if (live) acc[j] = __builtin_fmaf(da[j], t[j], acc[j]); }
+#pragma unroll
+        for (int o2 = 8; o2 > 0; o2 >>= 1) dot += __shfl_xor(dot, o2);
+        dot *= (1.f / 128.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (e)(r * (da[j] * (float)wv[j] - t[j] * dot));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (e)da[j];
+      }
+      if (live) *reinterpret_cast<v8*>(dx + h * 128) = o;
+    }
   }
   if (w_) {                                              // dw partial [gridDim.x, 128]
 #pragma unroll
@@ -389,6 +413,55 @@ __global__ __launch_bounds__(256) void transpose_kernel(const char* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// out[i] = cast( sum_s part[s * stride + i]  (+ extra[i]) ),  fp32 sums: the reduction of the per-workgroup weight-gradient partials of
+// the norm kernels above (many slabs of H values) and of the split-K weight-gradient GEMM (a few slabs of out*in values), fused with the
+// rounding to the parameter dtype.
+//   tall form: a workgroup of 16 waves owns 64 columns; wave w sums slabs w, w+16, ... (8 loads in flight), LDS combines the 16.
+template <int DT>
+__global__ __launch_bounds__(1024) void sum_slabs_tall_kernel(const float* __restrict__ part, int64_t slabs, int64_t n, int64_t stride,
+                                                              const float* __restrict__ extra, void* __restrict__ out_) {
+  using e = typename ETy<DT>::e;
+  __shared__ float red[16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t col = (int64_t)blockIdx.x * 64 + lane;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  if (col < n) {
+    int64_t s = wave;
+    for (; s + 16 * 7 < slabs; s += 16 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += part[(s + 16 * u) * stride + col];
+    }
+    for (; s < slabs; s += 16) acc[0] += part[s * stride + col];
+  }
+  red[wave * 64 + lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (wave == 0 && col < n) {
+    float t = extra ? extra[col] : 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w * 64 + lane];
+    reinterpret_cast<e*>(out_)[col] = (e)t;
+  }
+}
+//   flat form (slabs <= 16): one output element group of 4 per lane, slabs summed in order.
+template <int DT>
+__global__ __launch_bounds__(256) void sum_slabs_flat_kernel(const float* __restrict__ part, int slabs, int64_t n4, int64_t stride,
+                                                             const float* __restrict__ extra, void* __restrict__ out_) {
+  using e = typename ETy<DT>::e;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef e e4 __attribute__((ext_vector_type(4)));
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f4 t = extra ? *reinterpret_cast<const f4*>(extra + 4 * i) : f4{0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < slabs; ++s2) t += *reinterpret_cast<const f4*>(part + s2 * stride + 4 * i);
+    e4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (e)t[j];
+    *reinterpret_cast<e4*>(reinterpret_cast<e*>(out_) + 4 * i) = o;
+  }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int row_blocks(int64_t rows, int per_block, int cap) { int64_t b = (rows + per_block - 1) / per_block; return (int)(b < cap ? (b > 0 ? b : 1) : cap); }
 
@@ -448,8 +521,16 @@ extern "C" int dta_qk_norm_rope_fwd(const void* x, const void* w, const float* c
   if (!x || !cos_sin || !y || T <= 0 || NH <= 0 || (w && !rstd)) return DTA_EINVAL;
   if (!row_dtype_ok(dtype) || head_dim != 128) return DTA_EUNSUPPORTED;
   if (!al16(x) || !al16(y) || (w && !al16(w)) || x_stride_t % 8) return DTA_EALIGN;
-  const int64_t n = (int64_t)T * NH;
-  DTA_DISPATCH(qk_norm_rope_fwd_kernel, (unsigned)((n + 15) / 16), x, w, cos_sin, y, rstd, n, NH, x_stride_t, eps);
+  hipStream_t st_ = static_cast<hipStream_t>(stream);
+  DTA_REFUSE_IF_PRIOR_ERROR();
+#define DTA_QK_FWD(HPL_)                                                                                                       \
+  do { const int64_t n = (int64_t)T * (NH / HPL_); const dim3 grid((unsigned)((n + 15) / 16)), block(256);                   \
+       if (dtype == DTA_BF16) hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<DTA_BF16, HPL_>), grid, block, 0, st_, x, w, cos_sin, y, rstd, n, NH, x_stride_t, eps); \
+       else if (dtype == DTA_F16) hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<DTA_F16, HPL_>), grid, block, 0, st_, x, w, cos_sin, y, rstd, n, NH, x_stride_t, eps); \
+       else hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<DTA_F32, HPL_>), grid, block, 0, st_, x, w, cos_sin, y, rstd, n, NH, x_stride_t, eps); } while (0)
+  if (NH % 4 == 0) DTA_QK_FWD(4); else DTA_QK_FWD(1);
+#undef DTA_QK_FWD
+  return DTA_LAUNCH_STATUS();
 }
 
 /* dw_partial: float [dta_qk_norm_rope_bwd_blocks(T*NH), 128] (ignored when w == NULL). */
@@ -461,8 +542,18 @@ extern "C" int dta_qk_norm_rope_bwd(const void* x, const void* w, const float* c
   if (!row_dtype_ok(dtype) || head_dim != 128) return DTA_EUNSUPPORTED;
   if (!al16(dy) || !al16(dx) || (w && (!al16(w) || !al16(x))) || x_stride_t % 8 || dy_stride_t % 8 || dy_stride_h % 8 || dx_stride_t % 8) return DTA_EALIGN;
   if (dx_stride_t < (int64_t)NH * 128) return DTA_EINVAL;
-  const int64_t n = (int64_t)T * NH;
-  DTA_DISPATCH(qk_norm_rope_bwd_kernel, row_blocks(n, 16, 1024), x, w, cos_sin, dy, rstd, dx, dw_partial, n, NH, x_stride_t, dy_stride_t, dy_stride_h, dx_stride_t);
+  hipStream_t st_ = static_cast<hipStream_t>(stream);
+  DTA_REFUSE_IF_PRIOR_ERROR();
+  // the grid - and with it the number of dw_partial rows the caller sized from dta_qk_norm_rope_bwd_blocks(T*NH) - does not depend on HPL
+  const dim3 grid(row_blocks((int64_t)T * NH, 16, 1024)), block(256);
+#define DTA_QK_BWD(HPL_)                                                                                                       \
+  do { const int64_t n = (int64_t)T * (NH / HPL_);                                                                            \
+       if (dtype == DTA_BF16) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<DTA_BF16, HPL_>), grid, block, 0, st_, x, w, cos_sin, dy, rstd, dx, dw_partial, n, NH, x_stride_t, dy_stride_t, dy_stride_h, dx_stride_t); \
+       else if (dtype == DTA_F16) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<DTA_F16, HPL_>), grid, block, 0, st_, x, w, cos_sin, dy, rstd, dx, dw_partial, n, NH, x_stride_t, dy_stride_t, dy_stride_h, dx_stride_t); \
+       else hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<DTA_F32, HPL_>), grid, block, 0, st_, x, w, cos_sin, dy, rstd, dx, dw_partial, n, NH, x_stride_t, dy_stride_t, dy_stride_h, dx_stride_t); } while (0)
+  if (NH % 4 == 0) DTA_QK_BWD(4); else DTA_QK_BWD(1);
+#undef DTA_QK_BWD
+  return DTA_LAUNCH_STATUS();
 }
 
 extern "C" int dta_swiglu_fwd(const void* gate, const void* up, void* y, int64_t rows, int32_t cols, int64_t ld, int32_t dtype, void* stream) {
@@ -495,5 +586,27 @@ extern "C" int dta_transpose(const void* in, void* out, int64_t rows, int64_t co
   if (grid.y > 65535) return DTA_EUNSUPPORTED;
   if (elem_size == 2) hipLaunchKernelGGL(transpose_kernel<2>, grid, block, 0, st_, (const char*)in, (char*)out, rows, cols, ld_in, ld_out);
   else hipLaunchKernelGGL(transpose_kernel<4>, grid, block, 0, st_, (const char*)in, (char*)out, rows, cols, ld_in, ld_out);
+  return DTA_LAUNCH_STATUS();
+}
+
+extern "C" int dta_sum_slabs(const float* part, int64_t slabs, int64_t n, int64_t slab_stride, const float* extra, void* out, int32_t out_dtype,
+                             void* stream) {
+  if (!part || !out || slabs <= 0 || n <= 0 || slab_stride < n) return DTA_EINVAL;
+  if (!row_dtype_ok(out_dtype)) return DTA_EUNSUPPORTED;
+  hipStream_t st_ = static_cast<hipStream_t>(stream);
+  DTA_REFUSE_IF_PRIOR_ERROR();
+  const bool flat = slabs <= 16 && n % 4 == 0 && slab_stride % 4 == 0 && al16(part) && al16(out) && (!extra || al16(extra));
+  if (flat) {
+    const dim3 grid(row_blocks(n / 4, 256, 8192)), block(256);
+    if (out_dtype == DTA_BF16) hipLaunchKernelGGL(sum_slabs_flat_kernel<DTA_BF16>, grid, block, 0, st_, part, (int)slabs, n / 4, slab_stride, extra, out);
+    else if (out_dtype == DTA_F16) hipLaunchKernelGGL(sum_slabs_flat_kernel<DTA_F16>, grid, block, 0, st_, part, (int)slabs, n / 4, slab_stride, extra, out);
+    else hipLaunchKernelGGL(sum_slabs_flat_kernel<DTA_F32>, grid, block, 0, st_, part, (int)slabs, n / 4, slab_stride, extra, out);
+  } else {
+    if ((n + 63) / 64 > 0x7fffffff) return DTA_EUNSUPPORTED;
+    const dim3 grid((unsigned)((n + 63) / 64)), block(1024);
+    if (out_dtype == DTA_BF16) hipLaunchKernelGGL(sum_slabs_tall_kernel<DTA_BF16>, grid, block, 0, st_, part, slabs, n, slab_stride, extra, out);
+    else if (out_dtype == DTA_F16) hipLaunchKernelGGL(sum_slabs_tall_kernel<DTA_F16>, grid, block, 0, st_, part, slabs, n, slab_stride, extra, out);
+    else hipLaunchKernelGGL(sum_slabs_tall_kernel<DTA_F32>, grid, block, 0, st_, part, slabs, n, slab_stride, extra, out);
+  }
   return DTA_LAUNCH_STATUS();
 }

@@ -584,7 +584,7 @@ class _RMSNorm(torch.autograd.Function):
         _launch("dta_rmsnorm_bwd", (x2, w, dy2, gr), ptr(x2), ptr(w), ptr(dy2), ptr(gr), ptr(rstd), ptr(dx), ptr(part), R, H, _DT[x2.dtype],
                 nbytes=R * H * x2.element_size() * (4 if gr is not None else 3))
         dx = dx.view(dy.shape)
-        return dx, (dx if ctx.has_delta else None), part.sum(0).to(w.dtype), None
+        return dx, (dx if ctx.has_delta else None), sum_slabs(part, w.dtype), None
 
 
 def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
@@ -624,7 +624,7 @@ class _QKNormRope(torch.autograd.Function):
         _launch("dta_qk_norm_rope_bwd", (x, cos_sin, dy), ptr(x), ptr(w) if ctx.has_w else None, ptr(cos_sin), ptr(dy), ptr(rstd) if ctx.has_w else None,
                 ptr(dx), ptr(part), T, NH, D, x.stride(0), dy.stride(0), dy.stride(1), dx.stride(0), _DT[x.dtype],
                 nbytes=(3 if ctx.has_w else 2) * T * NH * D * x.element_size() + T * D * 4)
-        return dx, (part.sum(0).to(w.dtype) if ctx.has_w else None), None, None
+        return dx, (sum_slabs(part, w.dtype) if ctx.has_w else None), None, None
 
 
 class _QKVPrep(torch.autograd.Function):
@@ -664,7 +664,7 @@ class _QKVPrep(torch.autograd.Function):
             _launch("dta_qk_norm_rope_bwd", (qkv, cos_sin, dy), ptr(qkv[:, lo:lo + NH]), ptr(w) if has_w else None, ptr(cos_sin), ptr(dy),
                     ptr(rstd) if has_w else None, ptr(d[:, lo:lo + NH]), ptr(part), T, NH, D, qkv.stride(0), dy.stride(0), dy.stride(1), d.stride(0),
                     _DT[qkv.dtype], nbytes=(3 if has_w else 2) * T * NH * D * qkv.element_size() + T * D * 4)
-            dws.append(part.sum(0).to(w.dtype) if has_w else None)
+            dws.append(sum_slabs(part, w.dtype) if has_w else None)
         d[:, Hq + Hkv:].copy_(dv)
         return d, dws[0], dws[1], None, None, None, None
 
@@ -811,6 +811,17 @@ def clear_stack_rows_cache() -> None:
     _StackRows._cache.clear(); _StackRows._cached_bytes = 0
 
 
+def sum_slabs(part: torch.Tensor, out_dtype: torch.dtype, extra: torch.Tensor = None) -> torch.Tensor:
+    """part [S, ...] fp32 -> (Σ_s part[s] + extra) rounded once to `out_dtype`, ONE launch (torch: sum, add, cast = three, and its
+    column sum of a [2048, 1024] partial runs at 0.45 TB/s)."""
+    assert part.dtype == torch.float32 and part.is_contiguous() and (extra is None or (extra.dtype == torch.float32 and extra.is_contiguous()))
+    S, n = part.shape[0], part[0].numel()
+    assert extra is None or extra.numel() == n
+    out = torch.empty(part.shape[1:], dtype=out_dtype, device=part.device)
+    _launch("dta_sum_slabs", (part, extra, out), ptr(part), S, n, n, ptr(extra), ptr(out), _DT[out_dtype], nbytes=(S + (extra is not None)) * n * 4)
+    return out
+
+
 def transpose_2d(w: torch.Tensor) -> torch.Tensor:
     """[R, C] -> contiguous [C, R] by the HIP transpose kernel (16-byte accesses both ways; torch's transposing copy of a 311 MB head
     weight takes 2.5 ms, an HBM-rate copy 0.2)."""
@@ -869,24 +880,22 @@ WGRAD_SPLIT_K = int(_os.environ.get("DTA_WGRAD_SPLIT_K", "4"))      # slices of 
 def _wgrad(x: torch.Tensor, dy: torch.Tensor, transposed: bool) -> torch.Tensor:
     """dW[out, in] = dyᵀ[out, T] · x[T, in] - few output tiles, long K.  Qwen3-0.6B's q/k/v, o and down projections give 32-64 tiles of
     256x256 for 256 CUs with K = T ≈ 28 k: hipBLASLt runs them at 580-720 TFLOP/s.  A manual split-K fills the chip: the T rows are cut
-    into `WGRAD_SPLIT_K` equal slices (multiples of 256 rows), ONE batched GEMM forms the slices' products with fp32 outputs, and they
-    are summed in fp32 and rounded once (closer to the exact product than the single bf16-output GEMM) - 0.344 -> 0.260 ms (q/k/v),
+    into `WGRAD_SPLIT_K` equal slices (multiples of 64 rows), ONE batched GEMM forms the slices' products with fp32 outputs, and they
+    are summed in fp32 and rounded once by `sum_slabs` (closer to the exact product than the single bf16-output GEMM) - 0.344 -> 0.260 ms (q/k/v),
     0.203 -> 0.147 (o), 0.248 -> 0.201 (down) at T = 28 160 (scripts/gemm_splitk_probe.py; gate/up with 96 tiles does not gain and
     larger geometries have enough tiles).  `transposed`: form xᵀ·dy and return its transpose view (_Linear's layout choice)."""
     T = x.shape[0]
     a, b = (x, dy) if transposed else (dy, x)                    # result = aᵀ · b
     S = WGRAD_SPLIT_K
     tiles = -(-a.shape[1] // 256) * -(-b.shape[1] // 256)
-    per = (T // S) // 256 * 256 if S > 1 else 0
+    per = (T // S) // 64 * 64 if S > 1 else 0      # packed lengths are multiples of 256 from 2 048 rows on: nothing is left over at S = 4
     if S <= 1 or tiles > 64 or per < 2048 or not x.is_cuda or x.dtype == torch.float32:
         out = a.t() @ b
     else:
         body = per * S
         part = torch.bmm(a[:body].reshape(S, per, a.shape[1]).transpose(1, 2), b[:body].reshape(S, per, b.shape[1]), out_dtype=torch.float32)
-        acc = part.sum(0)
-        if body < T:
-            acc += torch.mm(a[body:].t(), b[body:], out_dtype=torch.float32)
-        out = acc.to(x.dtype)
+        rest = torch.mm(a[body:].t(), b[body:], out_dtype=torch.float32) if body < T else None
+        out = sum_slabs(part, x.dtype, rest)
     return out.t() if transposed else out
 
 

@@ -158,6 +158,7 @@ class _PackedTrie:
             pieces.append(np.arange(plan.seg_off[i], plan.seg_off[i + 1], dtype=np.int64))
             paths.append(np.concatenate(pieces))
         self.path_sizes = [p.size for p in paths]
+        self._paths_host = paths
         # ALL tables of the step in two asynchronous uploads out of page-locked staging (one int32, one int64 buffer)
         from ._staging import upload
         (seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, run_ptr_d, runs_d, kq_d, units_d, splits_d, fptr_d) = upload(
@@ -174,6 +175,18 @@ class _PackedTrie:
         self.meta = ops.TreeAttnMeta(T=T, subtree_end=self.subtree_end, run_ptr=run_ptr_d, runs=runs_d.view(-1, 4), ktile_qend=kq_d,
                                      dkv_units=units_d.view(-1, 4), dkv_splits=splits_d.view(-1, 4) if splits.shape[0] else None,
                                      n_slabs=n_slabs)
+
+    def sequence_rows(self, attach_lists):
+        """Packed row of every value the loss callbacks see, in callback order (leaf by leaf, the sequences folded onto it in attach-list
+        order): (rows of logprobs[:len-1] = depths 1..len-1, rows of entropy[:len] = depths 0..len-1), two int64 device vectors."""
+        lp_rows, ent_rows = [], []
+        for i, attach_list in enumerate(attach_lists):
+            path = self._paths_host[i]
+            for _, length in attach_list:
+                lp_rows.append(path[1:length]); ent_rows.append(path[:length])
+        from ._staging import upload
+        empty = np.zeros(0, np.int64)
+        return upload([np.concatenate(lp_rows) if lp_rows else empty, np.concatenate(ent_rows) if ent_rows else empty], self.tokens.device, np.int64)
 
     def _expand(self, tokens, leaf_off, seg_off, seg_d0, par_seg, brk_ptr, brk_depth, brk_end, M, T):
         from ._lib import check, lib, ptr
@@ -354,14 +367,43 @@ class TreeTrainingEngine:
     def _path_losses(self, packed, token_trie, lp, ent, loss_fn):
         """Σ over original sequences of loss_fn(logprobs[:len-1], entropy[:len], attachment) (tte:379-398).  The root paths of
         ALL leaves are gathered by one indexing kernel per vector; every sequence then gets VIEWS of its leaf's path (a
-        sequence folded onto a leaf is a prefix of it), and the user's callback runs per sequence as in the reference."""
-        lp_all, ent_all = lp[packed.path_cat], ent[packed.path_cat]
-        terms, o = [], 0
+        sequence folded onto a leaf is a prefix of it), and the user's callback runs per sequence as in the reference.
+        The views are autograd LEAVES cut off from the model's graph - as the reference's `logprobs`/`entropy` buffers are
+        (tte:383-398: detached storage, `grad_logprobs`/`grad_entropy` beside it): returns (total, [lp_view, ent_view, ...])
+        for `_backprop_paths`."""
+        lp_all, ent_all = lp.detach()[packed.path_cat], ent.detach()[packed.path_cat]
+        terms, leaves, o = [], [], 0
+        want = torch.is_grad_enabled() and (lp.requires_grad or ent.requires_grad)
         for i, attach_list in enumerate(token_trie.attach_lists):
             for attachment, length in attach_list:
-                terms.append(loss_fn(lp_all[o + 1:o + length], ent_all[o:o + length], attachment))
+                a, e = lp_all[o + 1:o + length], ent_all[o:o + length]
+                if want:
+                    a.requires_grad_(lp.requires_grad); e.requires_grad_(ent.requires_grad)
+                terms.append(loss_fn(a, e, attachment)); leaves += [a, e]
             o += packed.path_sizes[i]
-        return sum_loss_terms(terms, lp.device)
+        return sum_loss_terms(terms, lp.device), leaves
+
+    @staticmethod
+    def _backprop_paths(packed, token_trie, lp, ent, total, leaves):
+        """d(total)/d(params): the callbacks' small graph first (its leaves are the per-sequence views), then ONE accumulation of all
+        per-sequence gradients onto packed rows (a sorted, deterministic index_put: nested prefixes of a leaf's path add up) and ONE
+        backward through head and model - the reference assembles roots and gradients the same way (tte:404-440).  Without this the
+        autograd of 2 S slices costs 2 S zero-fills, copies and full-length additions (≈300 launches of 4-5 µs at S = 48)."""
+        total.backward()                               # fills .grad of the views (and of anything else the callbacks reached)
+        rows = None
+        roots, grads = [], []
+        for k, src in ((0, lp), (1, ent)):
+            gs = [t.grad for t in leaves[k::2]]
+            if not src.requires_grad or all(g is None for g in gs):
+                continue
+            if rows is None:
+                rows = packed.sequence_rows(token_trie.attach_lists)
+            vals = torch.cat([g if g is not None else torch.zeros_like(t) for g, t in zip(gs, leaves[k::2])])
+            acc = torch.zeros_like(src)
+            acc.index_put_((rows[k],), vals.to(acc.dtype), accumulate=True)
+            roots.append(src); grads.append(acc)
+        if roots:
+            torch.autograd.backward(roots, grads)
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -424,10 +466,10 @@ class TreeTrainingEngine:
             self.last_mode = "packed" if kept[0] >= self.n_layers else f"packed+recompute[{self.n_layers - kept[0]}/{self.n_layers}]"
         lp, ent = packed_logprob_entropy(h, head_weight(model), packed.tokens, packed.parent, True, max(chunk, 1),
                                          packed.fork_child, packed.fork_parent, self.tp_group, packed.fork_dev)
-        total = self._path_losses(packed, token_trie, lp, ent, loss_fn)
+        total, leaves = self._path_losses(packed, token_trie, lp, ent, loss_fn)
         if total is None:
             return 0.0
         if total.requires_grad:                     # (a callback that returns constants only leaves nothing to back-propagate)
-            total.backward()
+            self._backprop_paths(packed, token_trie, lp, ent, total, leaves)
         self.cur_len = 0
         return float(total.item())

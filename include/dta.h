@@ -214,6 +214,14 @@ int dta_swiglu_bwd(const void* gate, const void* up, const void* dy, void* dgate
  * torch.autograd.backward) run 12-25 % faster with the contraction index contiguous in both operands. */
 int dta_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, int32_t elem_size, void* stream);
 
+/* out[i] = round_to(out_dtype)( sum_{s < slabs} part[s * slab_stride + i]  + (extra ? extra[i] : 0) ),  i < n; all sums in fp32.
+ * The reduction of weight-gradient partials fused with the rounding to the parameter dtype: the per-workgroup dw partials of
+ * dta_rmsnorm_bwd / dta_qk_norm_rope_bwd (slabs = workgroups, n = H or 128) and the slices of the split-K weight-gradient GEMM
+ * (slabs = the split, n = out*in, extra = the product of the rows the equal slices leave over).  Stands where the reference's
+ * autograd sums a weight's gradient over all rows of a model call in one GEMM (tree_training_engine.py:440).  `out` may not alias
+ * `part` or `extra`.  Any n; the vector form is taken when slabs <= 16 and n, slab_stride are multiples of 4 with 16-byte aligned pointers. */
+int dta_sum_slabs(const float* part, int64_t slabs, int64_t n, int64_t slab_stride, const float* extra, void* out, int32_t out_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

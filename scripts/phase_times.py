@@ -23,7 +23,7 @@ for it in range(3):
     pk = _PackedTrie(trie, dev); t3 = sync()
     h = packed_hidden_states(model, pk.tokens, pk.depth, pk.meta, False); t4h = time.time(); t4 = sync()
     lp, ent = packed_logprob_entropy(h, head_weight(model), pk.tokens, pk.parent, True, 2048, pk.fork_child, pk.fork_parent); t5 = sync()
-    tot = eng._path_losses(pk, trie, lp, ent, bench.loss_fn); t6 = sync()
-    tot.backward(); t7h = time.time(); t7 = sync()
+    tot, leaves = eng._path_losses(pk, trie, lp, ent, bench.loss_fn); t6 = sync()
+    eng._backprop_paths(pk, trie, lp, ent, tot, leaves); t7h = time.time(); t7 = sync()
     print(f"iter {it}: trie {1e3*(t1-t0):.1f}  permute {1e3*(t2-t1):.1f}  pack {1e3*(t3-t2):.1f}  fwd {1e3*(t4-t3):.1f} (host enqueue {1e3*(t4h-t3):.1f})  "
           f"head {1e3*(t5-t4):.1f}  loss {1e3*(t6-t5):.1f}  bwd {1e3*(t7-t6):.1f} (host {1e3*(t7h-t6):.1f})  total {1e3*(t7-t0):.1f} ms", flush=True)

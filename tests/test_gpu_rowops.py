@@ -111,6 +111,23 @@ def test_transpose_kernel_bit_exact(R, C, dtype):
     assert y.shape == (C, R) and y.is_contiguous() and torch.equal(y, x.t().contiguous())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("shape,extra", [((2048, 1024), False), ((1024, 128), False), ((4, 3072, 1024), True), ((4, 1024, 2048), False), ((1, 8), False),
+                                         ((3, 7), True), ((16, 20), True), ((17, 20), True), ((300, 5120), False), ((2, 64, 6), True)])
+def test_sum_slabs_is_the_float64_sum_rounded_once(shape, extra, dtype):
+    """dta_sum_slabs (both forms: many slabs of a row, a few slabs of a matrix; with and without the left-over product): the fp32 sum
+    differs from the float64 sum by summation-order rounding only, and the result is rounded to the output dtype once."""
+    g = torch.Generator().manual_seed(sum(shape))
+    part = torch.randn(*shape, generator=g).to(DEV)
+    ex = torch.randn(*shape[1:], generator=g).to(DEV) if extra else None
+    got = ops.sum_slabs(part, dtype, ex)
+    want64 = part.double().sum(0) + (ex.double() if extra else 0.0)
+    assert got.shape == part.shape[1:] and got.dtype == dtype
+    eps = {torch.bfloat16: 2 ** -8, torch.float16: 2 ** -11, torch.float32: 2 ** -23}[dtype]
+    bound = eps * want64.abs() + 1e-6 * part.abs().double().sum(0) + 1e-30
+    assert ((got.double() - want64).abs() <= bound).all()
+
+
 def test_weight_copies_are_shared_inside_one_engine_call_only():
     """ops.weight_cache: inside the scope one transposed / stacked copy per weight (re-made when the weight's version moves); when the scope
     ends the copies are gone, and outside it nothing is cached - no entry can outlive the tensors it was keyed on."""
