@@ -249,10 +249,11 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_kernel(const void* __res
   }
 }
 
+// dx_ may be dy_ (in place): a lane writes exactly the 16-byte groups it read; its partner's values arrive through registers.
 template <int DT, int HPL>
 __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const void* __restrict__ x_, const void* __restrict__ w_, const float* __restrict__ cs,
-                                                               const void* __restrict__ dy_, const float* __restrict__ rstd,
-                                                               void* __restrict__ dx_, float* __restrict__ dw_part, int64_t n_units, int NH,
+                                                               const void* dy_, const float* __restrict__ rstd,
+                                                               void* dx_, float* __restrict__ dw_part, int64_t n_units, int NH,
                                                                int64_t x_st, int64_t dy_st_t, int64_t dy_st_h, int64_t dx_st) {
   using e = typename ETy<DT>::e; using v8 = typename ETy<DT>::v8;
   __shared__ float red[256 * 8];

@@ -155,12 +155,14 @@ def attn_fwd_raw(q, k, v, meta: TreeAttnMeta, scale: float):
     return out, lse, k, v
 
 
-def attn_bwd_raw(q, k, v, out, dout, lse, meta: TreeAttnMeta, scale: float, dk=None, dv=None, accumulate=False):
+def attn_bwd_raw(q, k, v, out, dout, lse, meta: TreeAttnMeta, scale: float, dk=None, dv=None, accumulate=False, dq=None):
+    """dq/dk/dv may be given as output buffers (row stride, head stride; dk and dv with the SAME strides)."""
     Tq, Hq, D = q.shape
     Tk, Hkv, _ = k.shape
     if dout.stride() != out.stride():
         dout = dout.contiguous(); out = out.contiguous()
-    dq = torch.empty((Tq, Hq, D), dtype=q.dtype, device=q.device)
+    if dq is None:
+        dq = torch.empty((Tq, Hq, D), dtype=q.dtype, device=q.device)
     if dk is None:
         dk = torch.empty((Tk, Hkv, D), dtype=q.dtype, device=q.device); dv = torch.empty_like(dk)
     delta = torch.empty((Hq, Tq), dtype=torch.float32, device=q.device)
@@ -211,6 +213,9 @@ class AttentionTape:
         return False
 
 
+ATTN_FUSED_GRAD = _os.environ.get("DTA_ATTN_FUSED_GRAD", "1") != "0"      # diagnostic A/B switch
+
+
 class _TreeAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, meta: TreeAttnMeta, scale: float):
@@ -230,7 +235,15 @@ class _TreeAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
-        dq, dk, dv = attn_bwd_raw(q, k, v, out, dout, lse, ctx.meta, ctx.scale)
+        Hq, Hkv = q.shape[1], k.shape[1]
+        if ATTN_FUSED_GRAD and q.shape[0] == k.shape[0]:
+            # the three gradients side by side in ONE [T, Hq+2Hkv, 128] buffer, the layout of the fused projection's gradient: _QKVPrep's
+            # backward then transforms dq and dk in place and hands the buffer on - no gather of dv (0.65 ms per step at tau2 size)
+            fused = torch.empty((q.shape[0], Hq + 2 * Hkv, q.shape[2]), dtype=q.dtype, device=q.device)
+            dq, dk, dv = fused[:, :Hq], fused[:, Hq:Hq + Hkv], fused[:, Hq + Hkv:]
+            attn_bwd_raw(q, k, v, out, dout, lse, ctx.meta, ctx.scale, dk=dk, dv=dv, dq=dq)
+        else:
+            dq, dk, dv = attn_bwd_raw(q, k, v, out, dout, lse, ctx.meta, ctx.scale)
         return dq, dk, dv, None, None
 
 
@@ -655,7 +668,14 @@ class _QKVPrep(torch.autograd.Function):
         qkv, wq, wk, cos_sin, rq, rk = ctx.saved_tensors
         Hq, Hkv = ctx.heads
         T, H3, D = qkv.shape
-        d = torch.empty_like(qkv)
+        base = dv._base
+        in_place = (base is not None and dq._base is base and dk._base is base and base.shape == qkv.shape and base.is_contiguous()
+                    and base.dtype == qkv.dtype and dq.shape == (T, Hq, D) and dk.shape == (T, Hkv, D) and dv.shape == (T, Hkv, D)
+                    and dq.stride() == dk.stride() == dv.stride() == (H3 * D, D, 1)
+                    and (dq.storage_offset(), dk.storage_offset(), dv.storage_offset()) == (0, Hq * D, (Hq + Hkv) * D))
+        # in_place: _TreeAttention's backward laid the three gradients out as this function's result; the kernel reads and writes the same
+        # 16 bytes per lane (partner values travel through registers), so dx may be dy
+        d = base if in_place else torch.empty_like(qkv)
         dws = []
         for lo, NH, w, rstd, has_w, dy in ((0, Hq, wq, rq, ctx.has_w[0], dq), (Hq, Hkv, wk, rk, ctx.has_w[1], dk)):
             if dy.stride(2) != 1:
@@ -665,7 +685,8 @@ class _QKVPrep(torch.autograd.Function):
                     ptr(rstd) if has_w else None, ptr(d[:, lo:lo + NH]), ptr(part), T, NH, D, qkv.stride(0), dy.stride(0), dy.stride(1), d.stride(0),
                     _DT[qkv.dtype], nbytes=(3 if has_w else 2) * T * NH * D * qkv.element_size() + T * D * 4)
             dws.append(sum_slabs(part, w.dtype) if has_w else None)
-        d[:, Hq + Hkv:].copy_(dv)
+        if not in_place:
+            d[:, Hq + Hkv:].copy_(dv)
         return d, dws[0], dws[1], None, None, None, None
 
 
@@ -896,7 +917,12 @@ def _wgrad(x: torch.Tensor, dy: torch.Tensor, transposed: bool) -> torch.Tensor:
         part = torch.bmm(a[:body].reshape(S, per, a.shape[1]).transpose(1, 2), b[:body].reshape(S, per, b.shape[1]), out_dtype=torch.float32)
         rest = torch.mm(a[body:].t(), b[body:], out_dtype=torch.float32) if body < T else None
         out = sum_slabs(part, x.dtype, rest)
-    return out.t() if transposed else out
+    if not transposed:
+        return out
+    # a contiguous [out, in]: autograd keeps it as the parameter's gradient as it is (a transposed VIEW is cloned by a strided copy that
+    # takes 13-18 us for a 4-6 MB matrix; this kernel 7)
+    V = 16 // out.element_size()
+    return transpose_2d(out) if out.is_cuda and out.shape[0] % V == 0 and out.shape[1] % V == 0 else out.t()
 
 
 class _Linear(torch.autograd.Function):

@@ -201,7 +201,7 @@ int dta_qk_norm_rope_bwd_blocks(int64_t n_heads_total);   /* rows of dw_partial 
 int dta_qk_norm_rope_bwd(const void* x, const void* w, const float* cos_sin, const void* dy, const float* rstd,
                          void* dx, float* dw_partial, int32_t T, int32_t NH, int32_t head_dim,
                          int64_t x_stride_t, int64_t dy_stride_t, int64_t dy_stride_h, int64_t dx_stride_t,
-                         int32_t dtype, void* stream);   /* dx: [T, NH, 128] with dx_stride_t elements between tokens (>= NH*128) */
+                         int32_t dtype, void* stream);   /* dx: [T, NH, 128] with dx_stride_t elements between tokens (>= NH*128); dx == dy (same strides) is allowed: in place */
 /* gate/up: [rows, cols] with `ld` elements between rows (they may be the two halves of one fused [rows, 2*cols]
  * projection output); y/dy: [rows, cols] contiguous; dgate/dup: `ld_grad` between rows. */
 int dta_swiglu_fwd(const void* gate, const void* up, void* y, int64_t rows, int32_t cols, int64_t ld, int32_t dtype, void* stream);

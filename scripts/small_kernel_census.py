@@ -21,6 +21,7 @@ def step(seed):
     seqs = synth.as_tensors(synth.tau2(seed=seed))
     trie = TokenTrie(seqs, [dict(bench.ATTACH) for _ in seqs])
     trie.backward_permute()
+    model.zero_grad(set_to_none=True)
     return eng.backward(model, trie, bench.loss_fn, 2048)
 
 

@@ -74,6 +74,33 @@ def test_qkv_prep_fused_buffer(T, Hq, Hkv, norm, dtype):
     _pair(glue(ops.qkv_prep, cs.to(DEV)), glue(hostmirror._cpu_qkv_prep, cs.float()), [qkv] + ([wq, wk] if norm else []), dtype)
 
 
+@pytest.mark.parametrize("T,Hq,Hkv,norm,dtype", [(1, 4, 4, True, torch.bfloat16), (300, 16, 8, True, torch.bfloat16), (129, 4, 4, False, torch.float16),
+                                                  (77, 3, 1, True, torch.bfloat16), (200, 16, 8, True, torch.float32)])
+def test_qkv_prep_backward_in_place_on_the_attention_gradient_buffer(T, Hq, Hkv, norm, dtype):
+    """When dq, dk, dv arrive side by side in one [T, Hq+2Hkv, 128] buffer (as _TreeAttention's backward lays them out) the head-norm/RoPE
+    backward runs in place on it; the result is bit-identical to the path with three separate gradient tensors."""
+    g = torch.Generator().manual_seed(T * 7 + Hq)
+    qkv = torch.randn(T, Hq + 2 * Hkv, 128, generator=g).to(dtype).to(DEV)
+    wq = (1 + 0.2 * torch.randn(128, generator=g)).to(dtype).to(DEV) if norm else None
+    wk = (1 + 0.2 * torch.randn(128, generator=g)).to(dtype).to(DEV) if norm else None
+    cs = ops.rope_cos_sin(torch.randint(0, 16384, (T,), generator=g), 128, 1e6).to(DEV)
+    grads = torch.randn(T, Hq + 2 * Hkv, 128, generator=g).to(dtype).to(DEV)
+    res = []
+    for fused in (False, True):
+        a = qkv.clone().requires_grad_()
+        ws = [w.clone().requires_grad_() for w in (wq, wk)] if norm else [None, None]
+        q, k, v = ops.qkv_prep(a, ws[0], ws[1], cs, 1e-6, Hq, Hkv)
+        buf = grads.clone()
+        views = (buf[:, :Hq], buf[:, Hq:Hq + Hkv], buf[:, Hq + Hkv:])
+        gq, gk, gv = views if fused else tuple(t.clone() for t in views)
+        torch.autograd.backward([q, k, v], [gq, gk, gv])
+        if fused and T > 1:
+            assert not torch.equal(buf, grads)                     # the buffer itself now holds the result
+        res.append([a.grad] + [w.grad for w in ws if w is not None])
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("shape,dtype", [((3, 8), torch.bfloat16), ((1000, 3072), torch.bfloat16), ((77, 9728), torch.float16)])
 def test_swiglu(shape, dtype):
     g = torch.Generator().manual_seed(shape[0])
