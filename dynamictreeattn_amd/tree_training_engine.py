@@ -212,6 +212,7 @@ class TreeTrainingEngine:
         self.n_kv_heads = getattr(model_config, "num_key_value_heads", 8)
         self.cur_len = 0                      # the packed engine is stateless between calls (reference: tte:550, 614-615)
         self.forkpos_list: List[int] = []
+        self._loss_host = None                      # page-locked landing place of a call's loss value
         self.returns: List[Optional[torch.Tensor]] = []
         self.last_packed: Optional[_PackedTrie] = None
         self.head_chunk = 2048
@@ -469,7 +470,20 @@ class TreeTrainingEngine:
         total, leaves = self._path_losses(packed, token_trie, lp, ent, loss_fn)
         if total is None:
             return 0.0
+        # the loss value leaves the device as soon as the forward has produced it (an asynchronous copy into page-locked memory) and the
+        # call returns when THAT copy has landed - with the backward launched but, on the device, still running: gradients are complete in
+        # stream order (an optimizer step, a gradient reduction or the next call simply queue behind them), and the host work of the next
+        # call (trie build, packing plan, uploads) overlaps this call's backward instead of leaving the device idle for it
+        landed = None
+        if total.is_cuda and os.environ.get("DTA_ASYNC_LOSS", "1") != "0":          # (env: diagnostic A/B switch)
+            if self._loss_host is None:
+                self._loss_host = torch.empty(1, dtype=torch.float32).pin_memory()
+            self._loss_host.copy_(total.detach().reshape(1).float(), non_blocking=True)
+            landed = torch.cuda.Event(); landed.record()
         if total.requires_grad:                     # (a callback that returns constants only leaves nothing to back-propagate)
             self._backprop_paths(packed, token_trie, lp, ent, total, leaves)
         self.cur_len = 0
-        return float(total.item())
+        if landed is None:
+            return float(total.item())
+        landed.synchronize()
+        return float(self._loss_host.item())
