@@ -12,6 +12,8 @@ raises.  (tests monkeypatch `_device_trie_arrays` with the oracle to exercise th
 """
 from __future__ import annotations
 
+import contextlib
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -30,6 +32,16 @@ def _sort_keys(inputs: Sequence[torch.Tensor]) -> List[bytes]:
             raise ValueError("token ids must be non-negative")
         keys.append(a.astype(">u8", copy=False).tobytes())
     return keys
+
+
+_TRIE_STREAMS: dict = {}
+
+
+def _trie_stream(device):
+    st = _TRIE_STREAMS.get(device.index)
+    if st is None:
+        st = _TRIE_STREAMS[device.index] = torch.cuda.Stream(device=device, priority=-1)
+    return st
 
 
 class _DeviceTokens:
@@ -123,8 +135,19 @@ class TokenTrie:
             keys = _sort_keys(inputs)
             order = list(range(S))
             order.sort(key=keys.__getitem__)
-        self._dev = _DeviceTokens(inputs, device)
-        leaf_lcp, unsorted, leaf_pos = _device_trie_arrays(self._dev, order, True)
+        # Host-resident token lists are uploaded and indexed on a SIDE stream of high priority: the device->host read of the LCP/leaf table
+        # below then waits for these two small kernels only, not for whatever the caller has queued on its own stream (an engine call
+        # returns with its backward still running - tree_training_engine.py `_backward` - and the next trie is built under it).
+        side = None
+        if device.type == "cuda" and os.environ.get("DTA_TRIE_STREAM", "1") != "0" and not any(isinstance(t, torch.Tensor) and t.is_cuda for t in inputs):
+            side = _trie_stream(device)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            self._dev = _DeviceTokens(inputs, device)
+            leaf_lcp, unsorted, leaf_pos = _device_trie_arrays(self._dev, order, True)
+        if side is not None:                                # the caller's stream consumes the token buffer (packing, embedding lookup)
+            main = torch.cuda.current_stream(device)
+            main.wait_stream(side)
+            self._dev.tokens.record_stream(main)
         if unsorted:
             raise ValueError("Input_ids not sorted in lexicographic order.")
         self.inputs, self.attach_lists, self._leaf_src = [], [], []
