@@ -37,12 +37,13 @@ if ks and b:
                            "ms_per_step": float(r["TotalDurationNs"]) / 1e6 / n_steps, "pct": float(r["Percentage"])} for r in rows[:14]]
 kt = first("trace/**/*kernel_trace.csv")
 if kt:
-    # GPU timeline per step: a step starts at its TokenTrie's lcp_adjacent_kernel; busy = union of the kernel intervals up to the next one
+    # GPU timeline per step: a step starts at its packed trie's preorder_meta_kernel (on the engine's stream; the TokenTrie's own kernels
+    # run on a side stream UNDER the previous step's backward); busy = union of the kernel intervals up to the next one
     recs = []
     for r in csv.DictReader(open(kt)):
         recs.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     recs.sort()
-    marks = [i for i, x in enumerate(recs) if "lcp_adjacent_kernel" in x[2]]
+    marks = [i for i, x in enumerate(recs) if "preorder_meta_kernel" in x[2]]
     steps = []
     for a, b in zip(marks[:-1], marks[1:]):
         seg = recs[a:b]
@@ -58,8 +59,8 @@ if kt:
     out["gpu_timeline_per_step"] = steady
     if steady:
         out["gpu_busy_frac_of_step"] = round(sum(x["gpu_busy_ms"] for x in steady) / sum(x["gpu_span_ms"] for x in steady), 4)
-        out["gpu_busy_note"] = ("from the kernel trace's own timestamps: step = one lcp_adjacent_kernel to the next (the span includes the host's trie build and "
-                                "planning at the step boundary); under rocprofv3 tracing, which slows the host side")
+        out["gpu_busy_note"] = ("from the kernel trace's own timestamps: step = one preorder_meta_kernel (packing, first kernel of an engine call on its stream) to the "
+                                "next; under rocprofv3 tracing, which slows the host side")
 hs = first("hip/**/*hip_api_stats.csv") or first("hip/**/*hip_stats.csv")
 hb = bench_line(os.path.join(root, "bench_under_hiptrace.json"))
 if hs and hb:
@@ -73,14 +74,15 @@ if hs and hb:
                    "synchronises twice per leg around the timed region; hipMemcpyAsync counts every H2D table upload and the D2H reads")
 ht = first("hip/**/*hip_api_trace.csv")
 if ht:
-    # steady-state host synchronisation per step: a step ends with the engine's loss.item() — the one long blocking copy
+    # steady-state host synchronisation per step: a step ends where the host waits for the loss value (hipEventSynchronize on the
+    # asynchronous copy issued before the backward was launched; a blocking hipMemcpyWithStream before round 3's second half)
     BLOCK = ("hipMemcpyWithStream", "hipStreamSynchronize", "hipDeviceSynchronize", "hipEventSynchronize", "hipMemcpy")
     ev = []
     for r in csv.DictReader(open(ht)):
         fn = r["Function"]
         if fn in BLOCK or "Launch" in fn:
             ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), fn))
-    ends = [i for i, (a, b, fn) in enumerate(ev) if fn == "hipMemcpyWithStream" and b - a > 20e6]
+    ends = [i for i, (a, b, fn) in enumerate(ev) if fn in ("hipMemcpyWithStream", "hipEventSynchronize") and b - a > 20e6]
     steps = []
     for a, b in zip(ends[:-1], ends[1:]):
         seg = ev[a + 1:b + 1]
@@ -91,6 +93,6 @@ if ht:
         steps.append({"launches": n_launch, "blocking_calls": {k: sum(1 for x in blk if x[2] == k) for k in sorted({x[2] for x in blk})},
                       "host_blocked_ms": round(sum(x[1] - x[0] for x in blk) / 1e6, 2), "step_ms": round((ev[b][1] - ev[a][1]) / 1e6, 2)})
     out["steady_state_steps_from_hip_trace"] = steps
-    out["steady_state_note"] = ("per step: hipMemcpyWithStream = device->host reads that wait for queued GPU work (the TokenTrie LCP/leaf table and the final "
-                                "loss.item()); everything else in a step is asynchronous launches and copies")
+    out["steady_state_note"] = ("per step: the host blocks in the TokenTrie's LCP/leaf-table read (side stream: two small kernels) and in the wait for the loss value "
+                                "(lands when the FORWARD is done; the backward is queued by then); everything else is asynchronous launches and copies")
 print(json.dumps(out, indent=1))
