@@ -458,6 +458,161 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
 }
 
 // =================================================================================================
+// forward, 8 waves with the two head groups HALF A TILE APART (A/B form 4).  Same work split as tree_attn_fwd_kernel<DT, 2> (waves 0-3 =
+// head 0, waves 4-7 = head 1 of the kv group, sharing the staged tiles, one barrier per tile), but the second group runs its tile body
+// ROTATED: in the interval of tile j it first multiplies P(j-1) - kept packed in 16 registers across the barrier - into V(j-1), then forms
+// S(j) and its softmax.  With both groups in the same order, the two waves of a SIMD meet in the same phase after every barrier (both in
+// the score MFMAs, then both in the exponentials, then both in the PV MFMAs); rotated, a wave's vector phase lies beside its partner's MFMA
+// phase in two of the three thirds of an interval.  V(j-1) has to outlive interval j, so the ring has THREE {K, V, subtree_end} slots
+// (99 KB) and the loop is unrolled over them.
+// =================================================================================================
+constexpr int FWD4_LDS = 3 * (2 * TILE_BYTES + SE_BYTES);
+template <int DT>
+__global__ __launch_bounds__(512, 2) void tree_attn_fwd4_kernel(AttnParams p) {
+  using T = Ty<DT>; using e = typename T::e; using v8 = typename T::v8; using v4 = typename T::v4;
+  constexpr int NW = 8, BUF = 2 * TILE_BYTES + SE_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[FWD4_LDS];
+
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hb = wave >> 2, rw = wave & 3;
+  const int bid = blockIdx.x;
+  const int hgroups = p.hgroups;
+  const int kvh = bid % p.Hkv; const int rest = bid / p.Hkv; const int hgb = rest % hgroups;
+  const int nqt = (p.Tq + DTA_QTILE - 1) / DTA_QTILE;
+  const int qt = nqt - 1 - rest / hgroups;
+  const int hq = kvh * p.group + p.head0 + hgb * 2 + hb;
+  const int q0 = qt * DTA_QTILE;
+  const int qrow = q0 + rw * 32 + r;
+  const int qrow_c = qrow < p.Tq ? qrow : p.Tq - 1;
+  const int qidx = p.q_offset + qrow;
+
+  TileIter it; it.runs = p.runs; it.diag_first_q = p.q_offset + q0;
+  if (p.runs) { it.ri = p.run_ptr[qt]; it.re = p.run_ptr[qt + 1]; if (!it.load_run()) return; }
+  else { it.ri = 0; it.re = 1; it.k0 = 0; it.flag = 1; int last = p.q_offset + (q0 + DTA_QTILE < p.Tq ? q0 + DTA_QTILE : p.Tq); it.kend = last < p.Tk ? last : p.Tk; if (it.kend <= 0) return; }
+
+  const e* qp = reinterpret_cast<const e*>(p.q) + (int64_t)qrow_c * p.q_st + (int64_t)hq * p.q_sh;
+  v8 qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const v8*>(qp + 16 * s + 8 * h);
+
+  const e* kbase = reinterpret_cast<const e*>(p.k) + (int64_t)kvh * p.kv_sh;
+  const e* vbase = reinterpret_cast<const e*>(p.v) + (int64_t)kvh * p.v_sh;
+  const FragOffs offs = frag_offsets(lane);
+  DTA_KV_OFFSETS(NW)
+
+  f32x16 O[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) O[db][g] = 0.f;
+  float m = -1e30f, lsum = 0.f;
+  const float c = p.scale * LOG2E;
+  v8 pk[4];                                   // group 1: P of the previous tile, packed
+  bool have_prev = false;
+
+  int ck0 = it.k0, ckend = it.kend; bool cmask = it.masked();
+  DTA_KV_DMA(smem, it.k0, NW)
+  bool has_next = it.advance();
+  DMA_WAIT(); __syncthreads();
+
+#define FWD4_SCORES(KS)                                                                                    \
+    const char* Ks = (KS);                                                                                 \
+    const int* se_s = reinterpret_cast<const int*>(Ks + 2 * TILE_BYTES);                                   \
+    f32x16 X[2];                                                                                           \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                     \
+      _Pragma("unroll") for (int g = 0; g < 16; ++g) X[kb][g] = 0.f;                                       \
+      _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                        \
+        X[kb] = T::mma(*reinterpret_cast<const v8*>(Ks + 8192 * kb + offs.row[s]), qf[s], X[kb]);         \
+    }                                                                                                      \
+    if (cmask) {                                                                                           \
+      const int qlim = qidx < ckend ? qidx : ckend - 1;                                                    \
+      _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                     \
+        _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                 \
+          const int kl = 32 * kb + 8 * gq + 4 * h;                                                         \
+          const int4 se4 = *reinterpret_cast<const int4*>(se_s + kl);                                      \
+          const int sev[4] = {se4.x, se4.y, se4.z, se4.w};                                                 \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+            const bool ok = (ck0 + kl + j <= qlim) && (qidx < sev[j]);                                     \
+            X[kb][4 * gq + j] = ok ? X[kb][4 * gq + j] : -INFINITY;                                        \
+          }                                                                                                \
+        }                                                                                                  \
+    }                                                                                                      \
+    float mx = max3(X[0][0], X[0][1], X[0][2]);                                                            \
+    _Pragma("unroll") for (int g = 3; g < 15; g += 2) mx = max3(mx, X[0][g], X[0][g + 1]);                 \
+    mx = fmaxf(mx, X[0][15]);                                                                              \
+    _Pragma("unroll") for (int g = 0; g < 16; g += 2) mx = max3(mx, X[1][g], X[1][g + 1]);                 \
+    mx = fmaxf(mx, __shfl_xor(mx, 32));                                                                    \
+    const float mc = mx * c;                                                                               \
+    if (__builtin_expect(__any(mc > m + FWD_THR), 0)) {                                                    \
+      const float mnew = fmaxf(m, mc);                                                                     \
+      const float alpha = fast_exp2(m - mnew);                                                             \
+      m = mnew; lsum *= alpha;                                                                             \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db)                                                     \
+        _Pragma("unroll") for (int g = 0; g < 16; ++g) O[db][g] *= alpha;                                  \
+    }                                                                                                      \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                       \
+      _Pragma("unroll") for (int g = 0; g < 16; ++g) { const float pv = fast_exp2(__builtin_fmaf(X[kb][g], c, -m)); lsum += pv; X[kb][g] = pv; }
+#define FWD4_PV(VS, PB)                                                                                    \
+    { const char* vs_ = (VS);                                                                              \
+    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                                                       \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) O[db] = T::mma(tr_frag_o<v8>(vs_ + 4096 * s4, offs, db), PB[s4], O[db]); }
+  // single-exit loops over a run-time ring slot (three compile-time slots x early exits made hipcc move the accumulators through scratch)
+  int slot = 0;                               // wave-uniform
+  bool more;
+  if (hb == 0) {
+    do {
+      const int nslot = slot == 2 ? 0 : slot + 1;
+      int nk0_ = 0, nkend_ = 0; bool nmask_ = false;
+      if (has_next) { nk0_ = it.k0; nkend_ = it.kend; nmask_ = it.masked(); DTA_KV_DMA(smem + nslot * BUF, it.k0, NW) }
+      FWD4_SCORES(smem + slot * BUF)
+      v8 pb_[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) pb_[s4] = pack_half<DT>(X[s4 >> 1], s4 & 1);
+      FWD4_PV(smem + slot * BUF + TILE_BYTES, pb_)
+      DMA_WAIT(); __syncthreads();
+      more = has_next;
+      if (more) { ck0 = nk0_; ckend = nkend_; cmask = nmask_; has_next = it.advance(); slot = nslot; }
+    } while (more);
+  } else {
+    int pslot = 0;
+    do {
+      const int nslot = slot == 2 ? 0 : slot + 1;
+      int nk0_ = 0, nkend_ = 0; bool nmask_ = false;
+      if (has_next) { nk0_ = it.k0; nkend_ = it.kend; nmask_ = it.masked(); DTA_KV_DMA(smem + nslot * BUF, it.k0, NW) }
+      if (have_prev) FWD4_PV(smem + pslot * BUF + TILE_BYTES, pk)
+      FWD4_SCORES(smem + slot * BUF)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) pk[s4] = pack_half<DT>(X[s4 >> 1], s4 & 1);
+      have_prev = true;
+      DMA_WAIT(); __syncthreads();
+      more = has_next;
+      pslot = slot;
+      if (more) { ck0 = nk0_; ckend = nkend_; cmask = nmask_; has_next = it.advance(); slot = nslot; }
+    } while (more);
+    FWD4_PV(smem + pslot * BUF + TILE_BYTES, pk)      // the deferred product of the last tile (its slot is not written again)
+  }
+#undef FWD4_PV
+#undef FWD4_SCORES
+
+  lsum += __shfl_xor(lsum, 32);
+  const float inv = 1.f / lsum;
+  if (qrow < p.Tq) {
+    e* op = reinterpret_cast<e*>(p.out) + (int64_t)qrow * p.o_st + (int64_t)hq * p.o_sh;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        v4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (e)(O[db][4 * gq + j] * inv);
+        *reinterpret_cast<v4*>(op + 32 * db + 8 * gq + 4 * h) = w;
+      }
+    if (h == 0) p.lse_w[(int64_t)hq * p.Tq + qrow] = m + __builtin_amdgcn_logf(lsum);
+  }
+}
+
+// =================================================================================================
 // forward, ONE wave per SIMD: a workgroup = 4 waves = 128 query rows, and every wave carries BOTH query heads of the kv group for its 32
 // rows (512 registers per lane: O 2 x 64, Q fragments 2 x 32, scores 2 x 32).
 //
@@ -1116,10 +1271,13 @@ extern "C" int dta_tree_attn_fwd_ex(const void* q, const void* k, const void* v,
   if (npair > 0) {
     p.hgroups = npair; p.head0 = 0;
     dim3 grid(nqt * Hkv * npair), block(512);
-    static const int form = [] { const char* e_ = getenv("DTA_FWD_FORM"); return e_ ? atoi(e_) : DTA_FWD_FORM_DEFAULT; }();   // 1: 8 waves, one head each; 3: 4 waves, two heads each, one wave per SIMD (A/B switch)
+    static const int form = [] { const char* e_ = getenv("DTA_FWD_FORM"); return e_ ? atoi(e_) : DTA_FWD_FORM_DEFAULT; }();   // 1: 8 waves, one head each; 3: 4 waves, two heads each, one wave per SIMD; 4: 8 waves, head groups half a tile apart (A/B switch)
     if (form == 3) {
       if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd3_kernel<DTA_BF16>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((tree_attn_fwd3_kernel<DTA_F16>), grid, dim3(256), 0, st, p);
+    } else if (form == 4) {
+      if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd4_kernel<DTA_BF16>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((tree_attn_fwd4_kernel<DTA_F16>), grid, block, 0, st, p);
     } else {
       if (dtype == DTA_BF16) hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_BF16, 2>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((tree_attn_fwd_kernel<DTA_F16, 2>), grid, block, 0, st, p);

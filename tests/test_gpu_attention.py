@@ -195,12 +195,13 @@ def test_full_size_config5_trie_attention_properties():
         assert rel(dv[path[excl:]], vs.grad.transpose(0, 1)[excl:]) <= 4e-3, leaf
 
 
-def test_one_wave_per_simd_forward_form_passes_the_same_cases():
-    """`DTA_FWD_FORM=3` selects the forward in which a workgroup is 4 waves and every wave carries BOTH query heads of a kv group (one wave
+@pytest.mark.parametrize("form", ["3", "4"])
+def test_alternative_forward_forms_pass_the_same_cases(form):
+    """`DTA_FWD_FORM=4`: the 8-wave forward whose second head group runs half a tile behind the first (three-slot ring).  `DTA_FWD_FORM=3` selects the forward in which a workgroup is 4 waves and every wave carries BOTH query heads of a kv group (one wave
     per SIMD, 512 registers).  The switch is read once per process, so the packed / stack / golden cases of this file run
     again in a child process under it."""
     import subprocess, sys
-    env = dict(os.environ, DTA_FWD_FORM="3")
+    env = dict(os.environ, DTA_FWD_FORM=form)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
                         "packed_tree_attention or stack_form or golden_attention or bitwise"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
