@@ -323,6 +323,28 @@ __device__ __forceinline__ uint32_t dma_src_off(int row, int img_row, int lane, 
 #define DTA_KV_DMA_PAIR(I, NW)                                                                             \
   dma_pair2(dok_[2 * (I)], dok_[2 * (I) + 1], dkb_, dov_[2 * (I)], dov_[2 * (I) + 1], dvb_, lds_addr(dbase_ + (wave * (16 / (NW)) + 2 * (I)) * 1024));
 
+// The 16 score MFMAs of a tile.  Default: the two key blocks' chains INTERLEAVED with the fragment reads one k-step ahead (every MFMA's
+// operand was requested two MFMAs earlier and consecutive MFMAs do not depend on each other); -DDTA_SCORE_ORDER=0: block after block
+// (hipcc then waits for each of the first eight fragment reads right after issuing it).
+#ifndef DTA_SCORE_ORDER
+#define DTA_SCORE_ORDER 1
+#endif
+#if DTA_SCORE_ORDER
+#define DTA_SCORE_MFMAS                                                                                    \
+    { v8 ka_ = *reinterpret_cast<const v8*>(Ks + offs.row[0]), kb2_ = *reinterpret_cast<const v8*>(Ks + 8192 + offs.row[0]); \
+      _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                      \
+        v8 na_ = ka_, nb_ = kb2_;                                                                          \
+        if (s < 7) { na_ = *reinterpret_cast<const v8*>(Ks + offs.row[s + 1]); nb_ = *reinterpret_cast<const v8*>(Ks + 8192 + offs.row[s + 1]); } \
+        X[0] = T::mma(ka_, qf[s], X[0]); X[1] = T::mma(kb2_, qf[s], X[1]);                                 \
+        ka_ = na_; kb2_ = nb_;                                                                             \
+      } }
+#else
+#define DTA_SCORE_MFMAS                                                                                    \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                       \
+      _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                        \
+        X[kb] = T::mma(*reinterpret_cast<const v8*>(Ks + 8192 * kb + offs.row[s]), qf[s], X[kb]);
+#endif
+
 // =================================================================================================
 // forward.  HPB = query heads of one kv group handled by a workgroup (waves 4*hb .. 4*hb+3 own head hb);
 // they share the staged K/V tiles.  One barrier per 64-key tile, LDS double buffered, tile loop unrolled
@@ -374,6 +396,11 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
   int ck0 = it.k0, ckend = it.kend; bool cmask = it.masked();
   DTA_KV_DMA(smem, it.k0, NW)
   bool has_next = it.advance();
+  // The Q fragments must be COMPLETE in hipcc's own book-keeping before the loop: it cannot see the asm DMA, but it does count the plain
+  // global loads of Q, and with them still "pending" at the loop header it put `s_waitcnt vmcnt(7) .. vmcnt(0)` in front of the first eight
+  // score MFMAs of the loop body - where vmcnt(0) also waits for the NEXT tile's DMA issued a few hundred cycles earlier.
+#pragma unroll
+  for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(qf[s]));
   DMA_WAIT(); __syncthreads();
 
   // one tile out of buffer BUFI (compile-time): prefetch the next tile into the other buffer, S^T, softmax, PV
@@ -386,11 +413,9 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
     const char* Ks = smem + (BUFI) * BUF; const char* Vs = Ks + TILE_BYTES;                                \
     const int* se_s = reinterpret_cast<const int*>(Ks + 2 * TILE_BYTES);                                   \
     f32x16 X[2];                                                                                           \
-    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                     \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                       \
       _Pragma("unroll") for (int g = 0; g < 16; ++g) X[kb][g] = 0.f;                                       \
-      _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                        \
-        X[kb] = T::mma(*reinterpret_cast<const v8*>(Ks + 8192 * kb + offs.row[s]), qf[s], X[kb]); \
-    }                                                                                                      \
+    DTA_SCORE_MFMAS                                                                                        \
     DTA_STAMP_AT(1)                                                                                        \
     if (cmask) {                                                                                           \
       const int qlim = qidx < ckend ? qidx : ckend - 1;      /* keys at or beyond the run end never count */ \
@@ -514,6 +539,11 @@ __global__ __launch_bounds__(512, 2) void tree_attn_fwd4_kernel(AttnParams p) {
   int ck0 = it.k0, ckend = it.kend; bool cmask = it.masked();
   DTA_KV_DMA(smem, it.k0, NW)
   bool has_next = it.advance();
+  // The Q fragments must be COMPLETE in hipcc's own book-keeping before the loop: it cannot see the asm DMA, but it does count the plain
+  // global loads of Q, and with them still "pending" at the loop header it put `s_waitcnt vmcnt(7) .. vmcnt(0)` in front of the first eight
+  // score MFMAs of the loop body - where vmcnt(0) also waits for the NEXT tile's DMA issued a few hundred cycles earlier.
+#pragma unroll
+  for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(qf[s]));
   DMA_WAIT(); __syncthreads();
 
 #define FWD4_SCORES(KS)                                                                                    \
