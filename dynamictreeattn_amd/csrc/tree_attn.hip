@@ -204,6 +204,11 @@ constexpr int SE_BYTES = 256;                                       // 64 x int3
 constexpr int QK_LDS = 2 * (2 * TILE_BYTES + SE_BYTES);            // double-buffered {K image, V image, se}
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float half_max(float x) {      // max(x, value of the lane 32 away) by v_permlane32_swap (no LDS round trip)
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 
 // Per-lane byte offsets of every fragment read inside one image, computed once: the XOR swizzle depends on the
 // lane only (row blocks of 32 and k-steps of 16 rows leave row&3 and (row>>2)&3 unchanged), so inside the tile
@@ -430,11 +435,10 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
           }                                                                                                \
         }                                                                                                  \
     }                                                                                                      \
-    float mx = max3(X[0][0], X[0][1], X[0][2]);                                                            \
-    _Pragma("unroll") for (int g = 3; g < 15; g += 2) mx = max3(mx, X[0][g], X[0][g + 1]);                 \
-    mx = fmaxf(mx, X[0][15]);                                                                              \
-    _Pragma("unroll") for (int g = 0; g < 16; g += 2) mx = max3(mx, X[1][g], X[1][g + 1]);                 \
-    mx = fmaxf(mx, __shfl_xor(mx, 32));                                                                    \
+    float mx = max3(X[0][0], X[0][1], X[0][2]), mx1 = max3(X[1][0], X[1][1], X[1][2]);   /* two independent chains */ \
+    _Pragma("unroll") for (int g = 3; g < 15; g += 2) { mx = max3(mx, X[0][g], X[0][g + 1]); mx1 = max3(mx1, X[1][g], X[1][g + 1]); } \
+    mx = max3(mx, X[0][15], mx1);                                                                          \
+    mx = half_max(fmaxf(mx, X[1][15]));        /* v_permlane32_swap: no LDS round trip (ds_bpermute + 6 address instructions before) */ \
     const float mc = mx * c;                                                                               \
     if (__any(mc > m + FWD_THR)) {             /* O is rescaled only when some row's maximum grew by more than the deferral threshold */ \
       const float mnew = fmaxf(m, mc);                                                                     \
@@ -568,11 +572,10 @@ __global__ __launch_bounds__(512, 2) void tree_attn_fwd4_kernel(AttnParams p) {
           }                                                                                                \
         }                                                                                                  \
     }                                                                                                      \
-    float mx = max3(X[0][0], X[0][1], X[0][2]);                                                            \
-    _Pragma("unroll") for (int g = 3; g < 15; g += 2) mx = max3(mx, X[0][g], X[0][g + 1]);                 \
-    mx = fmaxf(mx, X[0][15]);                                                                              \
-    _Pragma("unroll") for (int g = 0; g < 16; g += 2) mx = max3(mx, X[1][g], X[1][g + 1]);                 \
-    mx = fmaxf(mx, __shfl_xor(mx, 32));                                                                    \
+    float mx = max3(X[0][0], X[0][1], X[0][2]), mx1 = max3(X[1][0], X[1][1], X[1][2]);   /* two independent chains */ \
+    _Pragma("unroll") for (int g = 3; g < 15; g += 2) { mx = max3(mx, X[0][g], X[0][g + 1]); mx1 = max3(mx1, X[1][g], X[1][g + 1]); } \
+    mx = max3(mx, X[0][15], mx1);                                                                          \
+    mx = half_max(fmaxf(mx, X[1][15]));        /* v_permlane32_swap: no LDS round trip (ds_bpermute + 6 address instructions before) */ \
     const float mc = mx * c;                                                                               \
     if (__builtin_expect(__any(mc > m + FWD_THR), 0)) {                                                    \
       const float mnew = fmaxf(m, mc);                                                                     \
@@ -669,11 +672,6 @@ __device__ __forceinline__ void mfma_scores_done(f32x16& a, f32x16& b, f32x16& c
   asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c_), "+v"(d));
 }
 constexpr float FWD3_THR = FWD_THR;          // the reference maximum follows a tile's row maximum only when that grew by more than this (log2 domain: P <= 16): the rescale of the 128 O accumulators (AGPR <-> VGPR moves) becomes rare
-__device__ __forceinline__ float half_max(float x) {      // max(x, value of the lane 32 away) by v_permlane32_swap (no LDS round trip)
-  const unsigned u = __float_as_uint(x);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
 
 template <int DT>
 __global__ __launch_bounds__(256, 1) void tree_attn_fwd3_kernel(AttnParams p) {
@@ -918,10 +916,22 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_bwd_dq_kernel(AttnPara
         f32x16 X, DP;
 #pragma unroll
         for (int g = 0; g < 16; ++g) X[g] = 0.f;
+        {                                                  // fragment reads one k-step ahead of the MFMAs that use them
+          v8 kf_ = row_frag<v8>(Ks, 32 * kb + r, h), vf_ = row_frag<v8>(Vs, 32 * kb + r, h);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          X = T::mma(row_frag<v8>(Ks, 32 * kb + r, 2 * s + h), qf[s], X);
-          DP = T::mma(row_frag<v8>(Vs, 32 * kb + r, 2 * s + h), dof[s], s == 0 ? DI : DP);
+          for (int s = 0; s < 8; ++s) {
+            v8 nk_ = kf_, nv_ = vf_;
+            if (s < 7) { nk_ = row_frag<v8>(Ks, 32 * kb + r, 2 * s + 2 + h); nv_ = row_frag<v8>(Vs, 32 * kb + r, 2 * s + 2 + h); }
+            X = T::mma(kf_, qf[s], X);
+            DP = T::mma(vf_, dof[s], s == 0 ? DI : DP);
+            kf_ = nk_; vf_ = nv_;
+          }
+          // hipcc's scheduler otherwise sinks every read pair directly in front of its two MFMAs (one register pair re-used: each MFMA
+          // pair then waits a full LDS latency): pin the order {4 reads} {2 MFMA, 2 reads} x 6 {4 MFMA}
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+          for (int i_ = 0; i_ < 6; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         // dS^T / scale = P ∘ (dP − delta); the interval mask only on tiles of runs flagged partial
         if (cmask) {
