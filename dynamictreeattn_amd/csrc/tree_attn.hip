@@ -328,6 +328,19 @@ __device__ __forceinline__ uint32_t dma_src_off(int row, int img_row, int lane, 
 #define DTA_KV_DMA_PAIR(I, NW)                                                                             \
   dma_pair2(dok_[2 * (I)], dok_[2 * (I) + 1], dkb_, dov_[2 * (I)], dov_[2 * (I) + 1], dvb_, lds_addr(dbase_ + (wave * (16 / (NW)) + 2 * (I)) * 1024));
 
+// The first DTA_V_PRELOAD_N V fragments (k-step by k-step) requested BEFORE the row maximum (they do not depend on the softmax; hipcc otherwise issues them right in
+// front of the first PV MFMA, which then waits an LDS latency).  -DDTA_V_PRELOAD_N=0 disables.
+#ifndef DTA_V_PRELOAD_N
+#define DTA_V_PRELOAD_N 4
+#endif
+#if DTA_V_PRELOAD_N
+#define DTA_V_PRELOAD v8 vpre_[DTA_V_PRELOAD_N]; _Pragma("unroll") for (int i_ = 0; i_ < DTA_V_PRELOAD_N; ++i_) { vpre_[i_] = tr_frag_o<v8>(Vs + 4096 * (i_ >> 2), offs, i_ & 3); asm volatile("" : "+v"(vpre_[i_])); }
+#define DTA_V_FRAG(S4, DB) ((4 * (S4) + (DB) < DTA_V_PRELOAD_N) ? vpre_[4 * (S4) + (DB) < DTA_V_PRELOAD_N ? 4 * (S4) + (DB) : 0] : tr_frag_o<v8>(Vs + 4096 * (S4), offs, (DB)))
+#else
+#define DTA_V_PRELOAD
+#define DTA_V_FRAG(S4, DB) tr_frag_o<v8>(Vs + 4096 * (S4), offs, (DB))
+#endif
+
 // The 16 score MFMAs of a tile.  Default: the two key blocks' chains INTERLEAVED with the fragment reads one k-step ahead (every MFMA's
 // operand was requested two MFMAs earlier and consecutive MFMAs do not depend on each other); -DDTA_SCORE_ORDER=0: block after block
 // (hipcc then waits for each of the first eight fragment reads right after issuing it).
@@ -435,6 +448,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
           }                                                                                                \
         }                                                                                                  \
     }                                                                                                      \
+    DTA_V_PRELOAD                                                                                          \
     float mx = max3(X[0][0], X[0][1], X[0][2]), mx1 = max3(X[1][0], X[1][1], X[1][2]);   /* two independent chains */ \
     _Pragma("unroll") for (int g = 3; g < 15; g += 2) { mx = max3(mx, X[0][g], X[0][g + 1]); mx1 = max3(mx1, X[1][g], X[1][g + 1]); } \
     mx = max3(mx, X[0][15], mx1);                                                                          \
@@ -452,7 +466,7 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_fwd_kernel(AttnParams 
       _Pragma("unroll") for (int g = 0; g < 16; ++g) { const float pv = fast_exp2(__builtin_fmaf(X[kb][g], c, -m)); lsum += pv; X[kb][g] = pv; } \
     _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                     \
       const v8 pb = pack_half<DT>(X[s4 >> 1], s4 & 1);                                                     \
-      _Pragma("unroll") for (int db = 0; db < 4; ++db) O[db] = T::mma(tr_frag_o<v8>(Vs + 4096 * s4, offs, db), pb, O[db]); \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) O[db] = T::mma(DTA_V_FRAG(s4, db), pb, O[db]);      \
     }                                                                                                      \
     DTA_STAMP_AT(3)                                                                                        \
     DMA_WAIT(); __syncthreads();               /* the next tile has landed in every wave's view */          \
@@ -990,6 +1004,20 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_bwd_dq_kernel(AttnPara
 // the K/V fragments (pure MFMA B operands) live in LDS in fragment order (one lane-linear, conflict-free ds_read_b128
 // per use) instead of 64 registers.  The groups' partial dK/dV are summed through LDS in a fixed order at the end.
 // -------------------------------------------------------------------------------------------------
+// dkv2's S / dP chains: hipcc runs the eight dP MFMAs and then the eight S MFMAs as two dependent chains and issues every operand read
+// directly in front of the MFMA that uses it.  -DDTA_KV2_PIN=1 pins {delta row + operands of two k-steps} {2 MFMA, 4 reads} x 6 {4 MFMA}.
+#ifndef DTA_KV2_PIN
+#define DTA_KV2_PIN 0
+#endif
+#if DTA_KV2_PIN
+#define DTA_KV2_PIN_ORDER                                                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); } \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#else
+#define DTA_KV2_PIN_ORDER
+#endif
+
 constexpr int KV2_FRAGS = 4 * 16384;                                // 4 key slots x {K: 8 fragments x 1 KiB, V: 8 x 1 KiB}
 constexpr int KV2_BUF = 2 * TILE_BYTES + 512;
 constexpr int KV2_LDS = KV2_FRAGS + 2 * KV2_BUF + 16;                   // + se_min[4]: ONE __shared__ object (a second one makes hipcc drain vmcnt in front of every LDS read)
@@ -1115,6 +1143,7 @@ __global__ __launch_bounds__(512, 2) void tree_attn_bwd_dkv2_kernel(AttnParams p
       const v8 vfs = *reinterpret_cast<const v8*>(kvs + 8192 + s * 1024 + lane * 16);                      \
       S = T::mma(aq, kfs, S); DP = T::mma(ad, vfs, DP);                                                    \
     }                                                                                                      \
+    DTA_KV2_PIN_ORDER                                                                                      \
     float nl[16];                                                                                          \
     _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                     \
       const float4 l4 = *reinterpret_cast<const float4*>(rc + 32 * gq);                                    \
