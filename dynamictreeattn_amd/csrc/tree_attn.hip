@@ -1004,12 +1004,17 @@ __global__ __launch_bounds__(256 * HPB, 2) void tree_attn_bwd_dq_kernel(AttnPara
 // the K/V fragments (pure MFMA B operands) live in LDS in fragment order (one lane-linear, conflict-free ds_read_b128
 // per use) instead of 64 registers.  The groups' partial dK/dV are summed through LDS in a fixed order at the end.
 // -------------------------------------------------------------------------------------------------
-// dkv2's S / dP chains: hipcc runs the eight dP MFMAs and then the eight S MFMAs as two dependent chains and issues every operand read
-// directly in front of the MFMA that uses it.  -DDTA_KV2_PIN=1 pins {delta row + operands of two k-steps} {2 MFMA, 4 reads} x 6 {4 MFMA}.
+// dkv2's S / dP chains: left alone (-DDTA_KV2_PIN=0) hipcc runs most of the dP MFMAs and then the S MFMAs as two dependent chains, every operand
+// read directly in front of the MFMA that uses it.  Default 2: reads stay just in time but the two chains ALTERNATE (-1.0 %, three alternating
+// pairs on one box: 1.3407 -> 1.3272 ms); 1: {delta row + operands of two k-steps} {2 MFMA, 4 reads} x 6 {4 MFMA} - read bursts, 5 spills, 7 % slower.
 #ifndef DTA_KV2_PIN
-#define DTA_KV2_PIN 0
+#define DTA_KV2_PIN 2
 #endif
-#if DTA_KV2_PIN
+#if DTA_KV2_PIN == 2      /* just-in-time reads, but the two chains alternating: {delta row} {2 reads, 1 MFMA} x 16 */
+#define DTA_KV2_PIN_ORDER                                                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+#elif DTA_KV2_PIN
 #define DTA_KV2_PIN_ORDER                                                                                  \
     __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                                                    \
     _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); } \
