@@ -10,7 +10,7 @@ import torch
 import cases
 
 from dynamictreeattn_amd import dense, synth
-from dynamictreeattn_amd.model import Qwen3TreeLM
+from dynamictreeattn_amd.model import Qwen3TreeLM, make_config
 from dynamictreeattn_amd.token_trie import TokenTrie
 from dynamictreeattn_amd.tree_training_engine import TreeTrainingEngine
 from oracle import model_oracle as mo
@@ -349,6 +349,27 @@ def test_measured_recomputation_plan_runs_and_changes_nothing(monkeypatch):
         res.append((loss, e.last_mode, {n: p.grad.clone() for n, p in m.named_parameters()}))
     assert res[0][1] == "packed" and res[1][1].startswith("packed+recompute["), res[1][1]
     assert res[0][0] == res[1][0] and all(torch.equal(res[0][2][n], res[1][2][n]) for n in res[0][2])
+
+
+def test_recomputation_plan_charges_only_the_layers_it_recomputes(monkeypatch):
+    """`_full_layers` at Qwen3-14B geometry with 252 GB free and a measured 3.6 GB per full layer: the plan keeps the LARGEST number of
+    layers n for which n full layers + the stashes and kept attention outputs of the other 40 - n + two layers of working set + the LM
+    head fit 0.7 of the free HBM (the first form of round 3 subtracted a quarter of the free HBM and all 40 stashes whatever n, and kept 14)."""
+    import types
+    cfg = make_config(synth.QWEN3_14B)
+    e = TreeTrainingEngine(cfg, DEV, torch.bfloat16, 16384)
+    free = 252 * 10 ** 9
+    monkeypatch.setattr(e, "_free_hbm", lambda: free)
+    e._attn_keep_bytes()                                              # promises a quarter of `free` to kept attention outputs
+    T, d0 = 28160, int(3.6e9)
+    plan = e._full_layers(types.SimpleNamespace(config=cfg), T)
+    n = plan(d0)
+    head = int(2.0 * T * 151936 * 2 + 2 * 4 * 151936 * 5120)
+    stash_l, attn_l = 2 * T * 5120 * 2, T * 40 * (128 * 2 + 4)
+    need = lambda k: (k - 1) * d0 + (40 - k) * stash_l + min(e._attn_keep_planned, (40 - k) * attn_l)
+    avail = int(0.7 * free) - 2 * d0 - head
+    assert 25 <= n <= 40 and need(n) <= avail and (n == 40 or need(n + 1) > avail)
+    assert plan(10 ** 12) == 1                                        # a layer that does not fit at all: everything but layer 0 is recomputed
 
 
 def test_hf_attention_interface_plugin_matches_eager():
